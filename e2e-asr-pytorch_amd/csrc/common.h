@@ -1,0 +1,97 @@
+// Shared device/host helpers for libasr_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/asr_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define WAVE 64
+
+// ---- error plumbing (thread-local message, negative return codes) -------------------------
+void asr_set_error(const char* fmt, ...);
+
+#define ASR_REQUIRE(cond, code, ...)                                          \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            asr_set_error(__VA_ARGS__);                                       \
+            return (code);                                                    \
+        }                                                                     \
+    } while (0)
+
+#define ASR_LAUNCH_CHECK(name)                                                \
+    do {                                                                      \
+        hipError_t e_ = hipGetLastError();                                    \
+        if (e_ != hipSuccess) {                                               \
+            asr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return ASR_E_LAUNCH;                                              \
+        }                                                                     \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device math --------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ unsigned short f2bf_bits(float f) {
+    __bf16 v = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// log(exp(a)+exp(b)) that tolerates -inf on either side.
+__device__ __forceinline__ float logaddexpf_(float a, float b) {
+    float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + log1pf(expf(-fabsf(a - b)));
+}
+
+// MFMA wrappers: 16x16 output tile, f32 accumulate.
+//   bf16: K-step 32, lane l holds A[row l&15][k = 8*(l>>4)+j], B[k = 8*(l>>4)+j][col l&15], j=0..7
+//   f32 : K-step 4,  lane l holds A[row l&15][k = l>>4],       B[k = l>>4][col l&15]
+//   C/D : col = l&15, row = 4*(l>>4) + reg
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Philox4x32-10 counter RNG (one call -> 4 x u32). Used for dropout masks.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// keep(element idx) for dropout probability p: uniform u32 >= p * 2^32
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    uint32_t r[4];
+    uint64_t blk = idx >> 2;
+    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return r[idx & 3] >= thresh;
+}

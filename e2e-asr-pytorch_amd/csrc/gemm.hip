@@ -1,0 +1,276 @@
+// MFMA contraction kernel for every "large-M" linear map on the training path:
+//   C[i,j] (+)= act( sum_r opA(i,r) * opB(r,j) + bias[j] )
+// opA is stored either [i][r] (a_kc=1, reduction index contiguous) or [r][i] (a_kc=0);
+// opB is stored either [j][r] (b_kc=1) or [r][j] (b_kc=0).
+//   a_kc=1,b_kc=1 : y = x W^T          (nn.Linear forward; reference src/module.py:1079, src/asr.py:30,345)
+//   a_kc=1,b_kc=0 : dx = dy W          (its input gradient)
+//   a_kc=0,b_kc=0 : dW = dy^T x        (its weight gradient; reduction over B*T rows, split over blocks)
+// Operands live in HBM as fp32; PREC selects the MFMA: bf16 inputs (converted while staging into LDS,
+// f32 accumulate) or exact f32-input MFMA (parity mode).
+// Tile: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave 4x4 tiles of 16x16.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NT = 256;
+
+struct GemmP {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long sA, sB, sC;
+    int batch, splits;
+    int act, accum;
+    int seqT, bshift;
+    int vecA, vecB;
+};
+
+// One operand tile in LDS.  KC=true : image [row][k] (row = i or j), k contiguous.
+//                           KC=false: image [k][row], row contiguous (same as memory).
+template <bool BF16, bool KC> struct TileLayout;
+template <> struct TileLayout<true, true>   { static constexpr int LD = BK;      static constexpr int ELEMS = 128 * BK; };
+template <> struct TileLayout<true, false>  { static constexpr int LD = 128 + 8; static constexpr int ELEMS = BK * (128 + 8); };
+template <> struct TileLayout<false, true>  { static constexpr int LD = BK + 1;  static constexpr int ELEMS = 128 * (BK + 1); };
+template <> struct TileLayout<false, false> { static constexpr int LD = 128 + 4; static constexpr int ELEMS = BK * (128 + 4); };
+
+// Global -> registers: each thread fetches 4 x float4 of a 128 x 32 operand tile.
+//  KC : element (row, k) at base[row*ld + k];  thread -> row = tid/8 + 32q, k4 = (tid%8)*4
+//  !KC: element (row, k) at base[k*ld + row];  thread -> k = tid/32 + 8q, row4 = (tid%32)*4
+// rmask(k) gives validity of reduction index k (used for the shifted/masked wgrad operand).
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ base, long ld, int row0, int nrows,
+                                           int k0, int kend, int vec, int seqT, int shift, float4 (&r)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KC) {
+            int row = row0 + (tid >> 3) + 32 * q;
+            int k = k0 + (tid & 7) * 4;
+            if (row < nrows) {
+                const float* p = base + (long)row * ld + k;
+                if (vec && k + 3 < kend) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k + 0 < kend) v.x = p[0];
+                    if (k + 1 < kend) v.y = p[1];
+                    if (k + 2 < kend) v.z = p[2];
+                    if (k + 3 < kend) v.w = p[3];
+                }
+            }
+        } else {
+            int k = k0 + (tid >> 5) + 8 * q;
+            int row = row0 + (tid & 31) * 4;
+            bool ok = k < kend;
+            long ksrc = k;
+            if (seqT > 0) {
+                int t = k % seqT + shift;
+                ok = ok && (t >= 0) && (t < seqT);
+                ksrc = (long)k + shift;
+            }
+            if (ok) {
+                const float* p = base + ksrc * ld + row;
+                if (vec && row + 3 < nrows) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (row + 0 < nrows) v.x = p[0];
+                    if (row + 1 < nrows) v.y = p[1];
+                    if (row + 2 < nrows) v.z = p[2];
+                    if (row + 3 < nrows) v.w = p[3];
+                }
+            }
+        }
+        r[q] = v;
+    }
+}
+
+template <bool BF16, bool KC>
+__device__ __forceinline__ void stash_tile(void* lds, const float4 (&r)[4]) {
+    const int tid = threadIdx.x;
+    constexpr int LD = TileLayout<BF16, KC>::LD;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int a, b;   // a = leading index of the image, b = contiguous index
+        if (KC) { a = (tid >> 3) + 32 * q; b = (tid & 7) * 4; }
+        else    { a = (tid >> 5) + 8 * q;  b = (tid & 31) * 4; }
+        if (BF16) {
+            __bf16* s = reinterpret_cast<__bf16*>(lds) + a * LD + b;
+            bf16x4 v;
+            v[0] = (__bf16)r[q].x; v[1] = (__bf16)r[q].y; v[2] = (__bf16)r[q].z; v[3] = (__bf16)r[q].w;
+            *reinterpret_cast<bf16x4*>(s) = v;
+        } else {
+            float* s = reinterpret_cast<float*>(lds) + a * LD + b;
+            if (KC) { s[0] = r[q].x; s[1] = r[q].y; s[2] = r[q].z; s[3] = r[q].w; }
+            else    { *reinterpret_cast<float4*>(s) = r[q]; }
+        }
+    }
+}
+
+// Fragment of a 16-row slab starting at `row0` of the tile for MFMA k-step `ks`.
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag_bf16(const void* lds, int row0, int ks) {
+    const int lane = threadIdx.x & 63;
+    const __bf16* s = reinterpret_cast<const __bf16*>(lds);
+    const int row = row0 + (lane & 15);
+    const int k = ks * 32 + 8 * (lane >> 4);
+    if (KC) {
+        constexpr int LD = TileLayout<true, true>::LD;
+        return *reinterpret_cast<const bf16x8*>(s + row * LD + k);
+    } else {
+        constexpr int LD = TileLayout<true, false>::LD;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s[(k + j) * LD + row];
+        return v;
+    }
+}
+template <bool KC>
+__device__ __forceinline__ float frag_f32(const void* lds, int row0, int ks) {
+    const int lane = threadIdx.x & 63;
+    const float* s = reinterpret_cast<const float*>(lds);
+    const int row = row0 + (lane & 15);
+    const int k = ks * 4 + (lane >> 4);
+    if (KC) return s[row * TileLayout<false, true>::LD + k];
+    else    return s[k * TileLayout<false, false>::LD + row];
+}
+
+template <bool BF16, bool AKC, bool BKC>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+    constexpr int A_BYTES = TileLayout<BF16, AKC>::ELEMS * (BF16 ? 2 : 4);
+    constexpr int B_BYTES = TileLayout<BF16, BKC>::ELEMS * (BF16 ? 2 : 4);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+    void* As = smem;
+    void* Bs = smem + A_BYTES;
+
+    const int zb = blockIdx.z / p.splits;
+    const int zs = blockIdx.z % p.splits;
+    const float* A = p.A + (long)zb * p.sA;
+    const float* B = p.B + (long)zb * p.sB;
+    float* C = p.C + (long)zb * p.sC;
+
+    const int i0 = blockIdx.y * BM;
+    const int j0 = blockIdx.x * BN;
+
+    // reduction range of this split (multiple of BK)
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int per = (ktiles + p.splits - 1) / p.splits;
+    const int kt0 = zs * per;
+    const int kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[4], rb[4];
+    fetch_tile<AKC>(A, p.lda, i0, p.M, kt0 * BK, p.K, p.vecA, 0, 0, ra);
+    fetch_tile<BKC>(B, p.ldb, j0, p.N, kt0 * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb);
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        stash_tile<BF16, AKC>(As, ra);
+        stash_tile<BF16, BKC>(Bs, rb);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            fetch_tile<AKC>(A, p.lda, i0, p.M, (kt + 1) * BK, p.K, p.vecA, 0, 0, ra);
+            fetch_tile<BKC>(B, p.ldb, j0, p.N, (kt + 1) * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb);
+        }
+        if (BF16) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[a] = frag_bf16<AKC>(As, wr * 64 + a * 16, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = frag_bf16<BKC>(Bs, wc * 64 + b * 16, 0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                float fa[4], fb[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) fa[a] = frag_f32<AKC>(As, wr * 64 + a * 16, ks);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) fb[b] = frag_f32<BKC>(Bs, wc * 64 + b * 16, ks);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = mma16(fa[a], fb[b], acc[a][b]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map col = lane&15, row = 4*(lane>>4) + reg
+    const bool first_split = (zs == 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = j0 + wc * 64 + b * 16 + (lane & 15);
+            if (col >= p.N) continue;
+            const float bv = (p.bias != nullptr && first_split) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wr * 64 + a * 16 + 4 * (lane >> 4) + r;
+                if (row >= p.M) continue;
+                float v = acc[a][b][r] + bv;
+                float* dst = C + (long)row * p.ldc + col;
+                if (p.splits > 1) {
+                    atomicAdd(dst, v);
+                } else {
+                    if (p.act == ASR_ACT_TANH) v = tanhf(v);
+                    else if (p.act == ASR_ACT_RELU) v = fmaxf(v, 0.f);
+                    if (p.accum) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <bool BF16>
+int launch_gemm(const GemmP& p, int a_kc, int b_kc, hipStream_t st) {
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.batch * p.splits);
+    dim3 block(NT);
+    if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_kernel<BF16, true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_kernel<BF16, true, false>), grid, block, 0, st, p);
+    else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<BF16, false, false>), grid, block, 0, st, p);
+    else                     hipLaunchKernelGGL((gemm_kernel<BF16, false, true>), grid, block, 0, st, p);
+    ASR_LAUNCH_CHECK("asr_gemm");
+    return ASR_OK;
+}
+
+}  // namespace
+
+extern "C" int asr_gemm(const float* A, const float* B, float* C, const float* bias,
+                        int M, int N, int K, long lda, long ldb, long ldc,
+                        int a_kc, int b_kc, int act, int accum, int splits,
+                        int batch, long sA, long sB, long sC, int seqT, int bshift,
+                        int prec, asr_stream_t stream) {
+    ASR_REQUIRE(A && B && C, ASR_E_ARG, "asr_gemm: null operand");
+    ASR_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, ASR_E_ARG, "asr_gemm: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    ASR_REQUIRE(splits >= 1, ASR_E_ARG, "asr_gemm: splits must be >= 1");
+    ASR_REQUIRE(!(splits > 1 && (act != ASR_ACT_NONE || !accum)), ASR_E_ARG,
+                "asr_gemm: split reduction requires accum=1 and no activation");
+    ASR_REQUIRE(!(seqT > 0 && b_kc), ASR_E_ARG, "asr_gemm: shifted reduction rows need b_kc=0");
+    ASR_REQUIRE(prec == ASR_F32 || prec == ASR_BF16, ASR_E_ARG, "asr_gemm: bad prec %d", prec);
+    ASR_REQUIRE(ldc >= N, ASR_E_ARG, "asr_gemm: ldc < N");
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.sA = sA; p.sB = sB; p.sC = sC; p.batch = batch; p.splits = splits;
+    p.act = act; p.accum = accum; p.seqT = seqT; p.bshift = bshift;
+    p.vecA = (((uintptr_t)A & 15) == 0 && (lda % 4) == 0 && (sA % 4) == 0) ? 1 : 0;
+    p.vecB = (((uintptr_t)B & 15) == 0 && (ldb % 4) == 0 && (sB % 4) == 0) ? 1 : 0;
+    // the shifted operand reads rows at an offset; stays 16B aligned because ldb%4==0
+    hipStream_t st = (hipStream_t)stream;
+    return prec == ASR_BF16 ? launch_gemm<true>(p, a_kc, b_kc, st) : launch_gemm<false>(p, a_kc, b_kc, st);
+}

@@ -1,0 +1,116 @@
+"""Parity of the MFMA contraction (asr_gemm) against a plain fp32 torch matmul on the CPU.
+
+fp32 mode must match to accumulation-order noise; bf16 mode is compared with the same product on
+bf16-rounded operands (so a wrong fragment/lane map cannot hide behind the loose bf16 tolerance).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _ref(A, B, a_kc, b_kc, prec):
+    a = A if a_kc else A.transpose(-1, -2)
+    b = B.transpose(-1, -2) if b_kc else B
+    if prec == 1:
+        a, b = _bf(a), _bf(b)
+    return a.double() @ b.double()
+
+
+CASES = [
+    # M, N, K
+    (128, 128, 32), (130, 257, 160), (300, 31, 70), (64, 640, 640), (513, 96, 33), (17, 5, 3), (1000, 300, 941),
+]
+
+
+@pytest.mark.parametrize('prec', [0, 1])
+@pytest.mark.parametrize('a_kc,b_kc', [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize('M,N,K', CASES)
+def test_gemm_layouts(M, N, K, a_kc, b_kc, prec):
+    from src import hipabi
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K) if a_kc else (K, M), generator=g)
+    B = torch.randn((N, K) if b_kc else (K, N), generator=g)
+    ref = _ref(A, B, a_kc, b_kc, prec)
+    Ad, Bd = A.cuda(), B.cuda()
+    C = torch.full((M, N), float('nan'), device='cuda')
+    hipabi.gemm(Ad, Bd, C, M, N, K, A.shape[1], B.shape[1], N, a_kc=a_kc, b_kc=b_kc, prec=prec)
+    torch.cuda.synchronize()
+    err = (C.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-5 * max(scale, 1.0) * (K ** 0.5), (err, scale)
+
+
+@pytest.mark.parametrize('prec', [0, 1])
+def test_gemm_bias_act_accum(prec):
+    from src import hipabi
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 200, 70, 100
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    for act, fn in ((0, lambda x: x), (1, torch.tanh), (2, torch.relu)):
+        ref = fn(_ref(A, W, 1, 1, prec) + b.double())
+        C = torch.empty(M, N, device='cuda')
+        hipabi.gemm(A.cuda(), W.cuda(), C, M, N, K, K, K, N, bias=b.cuda(), act=act, prec=prec)
+        assert (C.cpu().double() - ref).abs().max().item() < 1e-4
+    # accumulate into existing C
+    C = C0.cuda()
+    hipabi.gemm(A.cuda(), W.cuda(), C, M, N, K, K, K, N, accum=1, prec=prec)
+    ref = C0.double() + _ref(A, W, 1, 1, prec)
+    assert (C.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize('prec', [0, 1])
+def test_gemm_split_reduction_and_views(prec):
+    """Weight-gradient form: dW[n,k] += sum_m dY[m,n] X[m,k] with dY a column slice of a wider buffer."""
+    from src import hipabi
+    g = torch.Generator().manual_seed(9)
+    Mr, N, K, wide = 1500, 96, 80, 256
+    dYw = torch.randn(Mr, wide, generator=g)
+    X = torch.randn(Mr, K, generator=g)
+    off = 64
+    dY = dYw[:, off:off + N]
+    ref = _ref(dY.contiguous(), X, 0, 0, prec)  # A stored [r][i]
+    C = torch.zeros(N, K, device='cuda')
+    dYd = dYw.cuda()
+    hipabi.gemm(dYd[:, off:], X.cuda(), C, N, K, Mr, wide, K, K, a_kc=0, b_kc=0, accum=1, splits=7, prec=prec)
+    assert (C.cpu().double() - ref).abs().max().item() < 2e-3 * (1 if prec == 0 else 1)
+
+
+@pytest.mark.parametrize('prec', [0, 1])
+@pytest.mark.parametrize('shift', [-1, 1])
+def test_gemm_shifted_rows(prec, shift):
+    """Recurrent weight gradient: sum over (b,t) of dG[b,t,:]^T h[b,t+shift,:], zero outside [0,T)."""
+    from src import hipabi
+    g = torch.Generator().manual_seed(11)
+    Bb, T, N, K = 3, 37, 64, 48
+    dG = torch.randn(Bb, T, N, generator=g)
+    H = torch.randn(Bb, T, K, generator=g)
+    Hs = torch.zeros_like(H)
+    if shift == -1:
+        Hs[:, 1:] = H[:, :-1]
+    else:
+        Hs[:, :-1] = H[:, 1:]
+    ref = _ref(dG.reshape(-1, N), Hs.reshape(-1, K), 0, 0, prec)
+    C = torch.zeros(N, K, device='cuda')
+    hipabi.gemm(dG.cuda(), H.cuda(), C, N, K, Bb * T, N, K, K, a_kc=0, b_kc=0, accum=1, splits=3,
+                seqT=T, bshift=shift, prec=prec)
+    assert (C.cpu().double() - ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize('prec', [0, 1])
+def test_gemm_batched(prec):
+    from src import hipabi
+    g = torch.Generator().manual_seed(13)
+    Bb, L, Tp, D = 4, 19, 75, 130
+    attn = torch.rand(Bb, L, Tp, generator=g)
+    dctx = torch.randn(Bb, L, D, generator=g)
+    ref = _ref(attn, dctx, 0, 0, prec)  # per batch attn^T dctx -> (Tp, D)
+    C = torch.zeros(Bb, Tp, D, device='cuda')
+    hipabi.gemm(attn.cuda(), dctx.cuda(), C, Tp, D, L, Tp, D, D, a_kc=0, b_kc=0, batch=Bb,
+                sA=L * Tp, sB=L * D, sC=Tp * D, prec=prec)
+    assert (C.cpu().double() - ref).abs().max().item() < 1e-3

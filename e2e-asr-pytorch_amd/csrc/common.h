@@ -95,3 +95,46 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32
     philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     return r[idx & 3] >= thresh;
 }
+
+// ---- small-M MFMA row dot products (recurrent / per-step matvecs) ------------------------------
+// 8 consecutive fp32 -> bf16x8 (guarded against the end of the row)
+__device__ __forceinline__ bf16x8 load8_bf16(const float* p, int k, int kend, bool ok, bool vec) {
+    bf16x8 v;
+    if (ok && vec && k + 7 < kend) {
+        float4 a = *reinterpret_cast<const float4*>(p + k);
+        float4 b = *reinterpret_cast<const float4*>(p + k + 4);
+        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+        v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)((ok && k + j < kend) ? p[k + j] : 0.f);
+    }
+    return v;
+}
+
+// acc += A(16 x K) * B(K x 16) where lane (l&15) addresses row `arow` of A and column-row `brow` of B,
+// both K-contiguous in memory; k-steps kbeg, kbeg+kstride, ...
+template <bool BF16>
+__device__ __forceinline__ f32x4 dot_rows(const float* arow, bool aok, const float* brow, bool bok, int K,
+                                          int ks_beg, int ks_stride, bool vec, f32x4 acc) {
+    const int q = (threadIdx.x & 63) >> 4;
+    if (BF16) {
+        const int nks = (K + 31) >> 5;
+        for (int ks = ks_beg; ks < nks; ks += ks_stride) {
+            const int k = ks * 32 + 8 * q;
+            bf16x8 a = load8_bf16(arow, k, K, aok, vec);
+            bf16x8 b = load8_bf16(brow, k, K, bok, vec);
+            acc = mma16(a, b, acc);
+        }
+    } else {
+        const int nks = (K + 3) >> 2;
+        for (int ks = ks_beg; ks < nks; ks += ks_stride) {
+            const int k = ks * 4 + q;
+            float a = (aok && k < K) ? arow[k] : 0.f;
+            float b = (bok && k < K) ? brow[k] : 0.f;
+            acc = mma16(a, b, acc);
+        }
+    }
+    return acc;
+}
+

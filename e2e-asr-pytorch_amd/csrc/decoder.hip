@@ -1,0 +1,823 @@
+// Location-aware attention + LSTM decoder ("speller") of the joint CTC-attention model: the whole
+// decode loop of ASR.forward (reference src/asr.py:123-175) and its backward as two C-ABI calls.
+//   per step t:  query = tanh(W_q hcat_{t-1} + b_q)                                     (src/asr.py:337)
+//                loc   = tanh(W_proj conv1d(prev_att))                                  (src/module.py:1163)
+//                e     = w_g . tanh(key + query + loc) + b_g ; /temperature ; mask ; softmax
+//                ctx   = attn . enc                                                     (src/module.py:1110-1117,1168)
+//                (h,c) = LSTM([emb(prev token), ctx])  per decoder layer                (src/asr.py:141-143,259-266)
+// after the loop: logits = W_c h_top + b_c for all steps at once (same arithmetic as the per-step
+// char_trans, src/asr.py:265).  Greedy mode (teacher == NULL) also evaluates logits/argmax per step.
+//
+// Step kernels are bandwidth/latency bound: key (B,T',A) and enc (B,T',E) are re-read every step and
+// stay resident in the 256 MB Infinity Cache between steps; one launch covers the whole batch.
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 64;  // encoder frames per workgroup in the energy kernels
+
+struct DecP {
+    asr_dec_dims_t d;
+    asr_dec_weights_t w;
+    asr_dec_state_t s;
+    const float* enc;
+    const int64_t* enc_len;
+};
+
+// ------------------------------------------------------------------------------------------------
+// token embedding rows:  xin[b,t,0:Dd] = emb[tokens[b,t]]
+// ------------------------------------------------------------------------------------------------
+__global__ void shift_tokens_kernel(const int64_t* __restrict__ teacher, int64_t* __restrict__ tokens, int B, int L, int Lt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    const int b = i / L, t = i % L;
+    tokens[i] = (t == 0) ? 0 : teacher[(long)b * Lt + (t - 1)];
+}
+
+__global__ void embed_kernel(const float* __restrict__ emb, const int64_t* __restrict__ tokens, float* __restrict__ xin,
+                             int B, int L, int Dd, int XW, int t0, int nt, int V) {
+    // rows (b, t) for t in [t0, t0+nt)
+    const long total = (long)B * nt * Dd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Dd);
+        const int t = t0 + (int)((i / Dd) % nt);
+        const int b = (int)(i / ((long)Dd * nt));
+        long tok = tokens[(long)b * L + t];
+        tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+        xin[((long)b * L + t) * XW + k] = emb[tok * Dd + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: query projection  q[b,t,:] = tanh(W_q hcat_{t-1}[b] + b_q);  one wave per 16 output columns
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(64) void dec_query_kernel(DecP p, int t) {
+    const asr_dec_dims_t& d = p.d;
+    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+    const int a = blockIdx.x * 16 + n;
+    const bool aok = a < d.A;
+    const float* wrow = p.w.Wq + (long)(aok ? a : 0) * d.Q;
+    const bool vec = (d.Q % 4) == 0;
+    for (int m0 = 0; m0 < d.B; m0 += 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            const int ab = m0 + n;
+            const bool rok = ab < d.B;
+            const float* hrow = p.s.hs + ((long)(rok ? ab : 0) * d.L + (t - 1)) * d.Q;
+            acc = dot_rows<BF16>(hrow, rok, wrow, aok, d.Q, 0, 1, vec, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = m0 + 4 * q + r;
+            if (aok && b < d.B) p.s.q[((long)b * d.L + t) * d.A + a] = tanhf(acc[r] + p.w.bq[a]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared tile prologue of the energy kernels: previous attention window + location convolution
+//   s_conv[k*TT + i] = sum_j Wconv[k][j] * prev_att[tau0 + i + j - Ks]
+// prev_att for t == 0 is the uniform initialisation 1/len over valid frames (src/module.py:1157-1160).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void conv_tile(const DecP& p, int b, int t, int tau0, float* s_pa, float* s_wc, float* s_conv) {
+    const asr_dec_dims_t& d = p.d;
+    const int taps = 2 * d.Ks + 1;
+    const int len = (int)p.enc_len[b];
+    const int win = TT + 2 * d.Ks;
+    const float* prev = (t > 0) ? p.s.att + ((long)b * d.L + (t - 1)) * d.Tp : nullptr;
+    for (int i = threadIdx.x; i < win; i += blockDim.x) {
+        const int tau = tau0 + i - d.Ks;
+        float v = 0.f;
+        if (tau >= 0 && tau < d.Tp) v = prev ? prev[tau] : (tau < len ? 1.f / (float)len : 0.f);
+        s_pa[i] = v;
+    }
+    for (int i = threadIdx.x; i < d.Kn * taps; i += blockDim.x) s_wc[i] = p.w.Wconv[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < d.Kn * TT; o += blockDim.x) {
+        const int i = o % TT, k = o / TT;
+        const float* wk = s_wc + k * taps;
+        float acc = 0.f;
+        for (int j = 0; j < taps; ++j) acc += wk[j] * s_pa[i + j];
+        s_conv[o] = acc;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: energies.  grid (ceil(T'/TT), B), 4 waves x 16 frames, lanes over the attention dimension.
+// ------------------------------------------------------------------------------------------------
+template <int KNMAX>
+__global__ __launch_bounds__(256) void att_energy_kernel(DecP p, int t) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const asr_dec_dims_t& d = p.d;
+    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
+    float* s_pa = smem_f;
+    float* s_wc = s_pa + (TT + 2 * d.Ks);
+    float* s_conv = s_wc + d.Kn * (2 * d.Ks + 1);
+    conv_tile(p, b, t, tau0, s_pa, s_wc, s_conv);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int len = (int)p.enc_len[b];
+    const float* qrow = p.s.q + ((long)b * d.L + t) * d.A;
+    float e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = 0.f;
+    for (int a = lane; a < d.A; a += 64) {
+        float wp[KNMAX];
+#pragma unroll
+        for (int k = 0; k < KNMAX; ++k) wp[k] = (k < d.Kn) ? p.w.Wproj[(long)a * d.Kn + k] : 0.f;
+        const float qa = qrow[a], wga = p.w.wg[a];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ti = wave * 16 + i;
+            const int tau = tau0 + ti;
+            if (tau < len) {
+                float lp = 0.f;
+#pragma unroll
+                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
+                const float u = tanhf(p.s.key[((long)b * d.Tp + tau) * d.A + a] + qa + tanhf(lp));
+                e[i] += wga * u;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float s = wave_sum(e[i]);
+        const int tau = tau0 + wave * 16 + i;
+        if (lane == 0 && tau < d.Tp)
+            p.s.energy[(long)b * d.Tp + tau] = (tau < len) ? (s + p.w.bg[0]) / d.temperature : -INFINITY;
+    }
+}
+
+// block-wide reductions over 256 threads (4 waves)
+__device__ __forceinline__ float block_max(float v, float* s4) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* s4) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: softmax over T' + context.  grid (ceil(E/64), B); every block redoes the (cheap) softmax of its
+// utterance and owns 64 columns of the context vector; block x == 0 also stores the attention row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void att_softmax_ctx_kernel(DecP p, int t) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    __shared__ float s4[4];
+    __shared__ float red[4][64];
+    const asr_dec_dims_t& d = p.d;
+    const int b = blockIdx.y, e0 = blockIdx.x * 64;
+    const int len = min((int)p.enc_len[b], d.Tp);
+    float* s_att = smem_f;  // [Tp]
+    const float* en = p.s.energy + (long)b * d.Tp;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < d.Tp; i += 256) { const float v = en[i]; s_att[i] = v; m = fmaxf(m, v); }
+    m = block_max(m, s4);
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < d.Tp; i += 256) { const float v = expf(s_att[i] - m); s_att[i] = v; sum += v; }
+    sum = block_sum(sum, s4);
+    const float inv = 1.f / sum;
+    for (int i = threadIdx.x; i < d.Tp; i += 256) {
+        const float a = s_att[i] * inv;
+        s_att[i] = a;
+        if (blockIdx.x == 0) p.s.att[((long)b * d.L + t) * d.Tp + i] = a;
+    }
+    __syncthreads();
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int ecol = e0 + col;
+    float acc = 0.f;
+    if (ecol < d.E) {
+        const float* ep = p.enc + (long)b * d.Tp * d.E + ecol;
+        for (int tau = grp; tau < len; tau += 4) acc += s_att[tau] * ep[(long)tau * d.E];
+    }
+    red[grp][col] = acc;
+    __syncthreads();
+    if (grp == 0 && ecol < d.E)
+        p.s.xin[((long)b * d.L + t) * (d.Dd + d.E) + d.Dd + ecol] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: one decoder LSTM layer, one step.  Same wave layout as the encoder step: column n of the tile is
+// gate n>>2 of hidden unit 4*blockIdx.x + (n&3).
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(64) void dec_cell_fwd_kernel(DecP p, int t, int l) {
+    const asr_dec_dims_t& d = p.d;
+    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+    const int g = n >> 2;
+    const int j = blockIdx.x * 4 + (n & 3);
+    const bool jok = j < d.Dd;
+    const int XW = d.Dd + d.E;
+    const int Kx = (l == 0) ? XW : d.Dd;
+    const float* wih = p.w.Wih[l] + ((long)g * d.Dd + (jok ? j : 0)) * Kx;
+    const float* whh = p.w.Whh[l] + ((long)g * d.Dd + (jok ? j : 0)) * d.Dd;
+    const int base = lane & ~12;
+    const long SW = (long)d.NL * d.Dd;  // row width of hs/cs
+    for (int m0 = 0; m0 < d.B; m0 += 16) {
+        const int ab = m0 + n;
+        const bool rok = ab < d.B;
+        const long rowi = (long)(rok ? ab : 0) * d.L + t;
+        const float* xrow = (l == 0) ? p.s.xin + rowi * XW : p.s.hs + rowi * SW + (long)(l - 1) * d.Dd;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = dot_rows<BF16>(xrow, rok, wih, jok, Kx, 0, 1, (Kx % 4) == 0 && (d.Dd % 4) == 0, acc);
+        if (t > 0) {
+            const float* hrow = p.s.hs + (rowi - 1) * SW + (long)l * d.Dd;
+            acc = dot_rows<BF16>(hrow, rok, whh, jok, d.Dd, 0, 1, (d.Dd % 4) == 0, acc);
+        }
+        const float bias = jok ? (p.w.bih[l][g * d.Dd + j] + p.w.bhh[l][g * d.Dd + j]) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = m0 + 4 * q + r;
+            const bool ok = jok && b < d.B;
+            const float pre = acc[r] + bias;
+            const float a = (g == 2) ? tanhf(pre) : sigmoidf_(pre);
+            const long ri = (long)(ok ? b : 0) * d.L + t;
+            if (ok) p.s.gates[(ri * d.NL + l) * 4 * d.Dd + g * d.Dd + j] = a;
+            const float ai = __shfl(a, base), af = __shfl(a, base + 4), ag = __shfl(a, base + 8), ao = __shfl(a, base + 12);
+            if (ok && g == 0) {
+                const float cp = (t > 0) ? p.s.cs[(ri - 1) * SW + (long)l * d.Dd + j] : 0.f;
+                const float cn = af * cp + ai * ag;
+                p.s.cs[ri * SW + (long)l * d.Dd + j] = cn;
+                p.s.hs[ri * SW + (long)l * d.Dd + j] = ao * tanhf(cn);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 (greedy decoding only): logits of step t, argmax, next input token.  One block per utterance.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_greedy_kernel(DecP p, int t) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];  // [V]
+    const asr_dec_dims_t& d = p.d;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* h = p.s.hs + (((long)b * d.L + t) * d.NL + (d.NL - 1)) * d.Dd;
+    for (int v = wave; v < d.V; v += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < d.Dd; k += 64) acc += h[k] * p.w.Wc[(long)v * d.Dd + k];
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            acc += p.w.bc[v];
+            smem_f[v] = acc;
+            p.s.logits[((long)b * d.L + t) * d.V + v] = acc;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && t + 1 < d.L) {
+        int best = 0;
+        float bv = smem_f[0];
+        for (int v = 1; v < d.V; ++v) if (smem_f[v] > bv) { bv = smem_f[v]; best = v; }
+        p.s.tokens[(long)b * d.L + t + 1] = best;
+    }
+}
+
+// =================================================================================================
+// backward
+// =================================================================================================
+struct DecB {
+    DecP f;
+    asr_dec_grads_t g;
+    float* dhs;        // (B,L,NL,Dd)   gradient wrt every h (accumulated in place)
+    float* dxin;       // (B,L,Dd+E)
+    float* dq;         // (B,L,A)       in: sum_tau du (atomics);  out: gradient wrt the query pre-activation
+    float* dkey;       // (B,T',A)
+    float* dattn;      // (B,T')        scratch of the current step
+    float* datt_next;  // (B,T')        gradient flowing into attn_t from step t+1's location conv
+    float* dconv;      // (B,Kn,T')
+    float* dcf;        // (NL,B,Dd)
+    float* wcatT[ASR_MAX_DEC_LAYERS];  // ((Kx+Dd) x 4Dd) transposed [W_ih ; W_hh]
+    float* wqT;        // (Q x A)
+    float* slots;      // (B*ntiles, SLOT) per-workgroup partial sums of d w_g, d W_proj, d b_g, d W_conv
+    int ntiles, slot;
+};
+
+// cell backward, elementwise part: dgates (in place over the activated gates) and the dc*f carry
+__global__ void dec_cell_bwd_elem_kernel(DecB p, int t, int l, int last) {
+    const asr_dec_dims_t& d = p.f.d;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.B * d.Dd) return;
+    const int b = i / d.Dd, j = i % d.Dd;
+    const long ri = (long)b * d.L + t;
+    const long SW = (long)d.NL * d.Dd;
+    float* g = p.f.s.gates + (ri * d.NL + l) * 4 * d.Dd;
+    const float gi = g[j], gf = g[d.Dd + j], gg = g[2 * d.Dd + j], go = g[3 * d.Dd + j];
+    const float ct = p.f.s.cs[ri * SW + (long)l * d.Dd + j];
+    const float cp = (t > 0) ? p.f.s.cs[(ri - 1) * SW + (long)l * d.Dd + j] : 0.f;
+    const float dh = p.dhs[ri * SW + (long)l * d.Dd + j];
+    const long ci = ((long)l * d.B + b) * d.Dd + j;
+    const float carry = last ? 0.f : p.dcf[ci];
+    const float tc = tanhf(ct);
+    const float dc = dh * go * (1.f - tc * tc) + carry;
+    g[j] = dc * gg * gi * (1.f - gi);
+    g[d.Dd + j] = dc * cp * gf * (1.f - gf);
+    g[2 * d.Dd + j] = dc * gi * (1.f - gg * gg);
+    g[3 * d.Dd + j] = dh * tc * go * (1.f - go);
+    p.dcf[ci] = dc * gf;
+}
+
+// cell backward, contraction part: [d_input | d_h_prev] = dgates (B x 4Dd) * [W_ih | W_hh]
+// block = 4 waves (split over the 4Dd reduction) x 16 output columns of the concatenated width Kx+Dd.
+template <bool BF16>
+__global__ __launch_bounds__(256) void dec_cell_bwd_mm_kernel(DecB p, int t, int l) {
+    __shared__ float red[4][256];
+    const asr_dec_dims_t& d = p.f.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int XW = d.Dd + d.E;
+    const int Kx = (l == 0) ? XW : d.Dd;
+    const int K = 4 * d.Dd;
+    const int c0 = blockIdx.x * 16;
+    const bool cok = (c0 + n) < Kx + d.Dd;
+    const float* wrow = p.wcatT[l] + (long)(cok ? c0 + n : 0) * K;
+    const long SW = (long)d.NL * d.Dd;
+    for (int m0 = 0; m0 < d.B; m0 += 16) {
+        const int ab = m0 + n;
+        const bool rok = ab < d.B;
+        const float* grow = p.f.s.gates + ((((long)(rok ? ab : 0) * d.L + t) * d.NL) + l) * K;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = dot_rows<BF16>(grow, rok, wrow, cok, K, wave, 4, true, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
+        __syncthreads();
+        const int row = tid >> 4, col = tid & 15;
+        const int b = m0 + row, c = c0 + col;
+        if (b < d.B && c < Kx + d.Dd) {
+            const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            const long ri = (long)b * d.L + t;
+            if (c < Kx) {
+                if (l == 0) p.dxin[ri * XW + c] = v;
+                else p.dhs[ri * SW + (long)(l - 1) * d.Dd + c] += v;
+            } else if (t > 0) {
+                p.dhs[(ri - 1) * SW + (long)l * d.Dd + (c - Kx)] += v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// B2a: dattn[b,tau] = dctx[b] . enc[b,tau] + datt_next[b,tau]
+__global__ __launch_bounds__(256) void att_bwd_dattn_kernel(DecB p, int t, int last) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];  // dctx [E]
+    const asr_dec_dims_t& d = p.f.d;
+    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int len = min((int)p.f.enc_len[b], d.Tp);
+    const float* dctx = p.dxin + ((long)b * d.L + t) * (d.Dd + d.E) + d.Dd;
+    for (int i = threadIdx.x; i < d.E; i += 256) smem_f[i] = dctx[i];
+    __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+        const int tau = tau0 + wave * 16 + i;
+        if (tau >= d.Tp) break;
+        float acc = 0.f;
+        if (tau < len) {
+            const float* er = p.f.enc + ((long)b * d.Tp + tau) * d.E;
+            for (int e = lane; e < d.E; e += 64) acc += smem_f[e] * er[e];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = (tau < len) ? acc : 0.f;
+            if (!last && tau < len) v += p.datt_next[(long)b * d.Tp + tau];
+            p.dattn[(long)b * d.Tp + tau] = v;
+        }
+    }
+}
+
+// B2b: softmax backward + energy backward for one (utterance, 64-frame tile)
+template <int KNMAX>
+__global__ __launch_bounds__(256) void att_bwd_energy_kernel(DecB p, int t) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    __shared__ float s4[4];
+    __shared__ float s_de[TT];
+    const asr_dec_dims_t& d = p.f.d;
+    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
+    const int taps = 2 * d.Ks + 1;
+    const int AP = d.A | 1;                        // odd row stride of the dloc tile (bank spread)
+    float* s_pa = smem_f;
+    float* s_wc = s_pa + (TT + 2 * d.Ks);
+    float* s_conv = s_wc + d.Kn * taps;
+    float* s_part = s_conv + d.Kn * TT;            // [A*(1+Kn)] block partial sums: d w_g, d W_proj
+    float* s_dl = s_part + d.A * (1 + d.Kn);       // [TT*AP] gradient wrt the loc pre-activation
+    conv_tile(p.f, b, t, tau0, s_pa, s_wc, s_conv);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int len = min((int)p.f.enc_len[b], d.Tp);
+    const float* att = p.f.s.att + ((long)b * d.L + t) * d.Tp;
+    const float* dat = p.dattn + (long)b * d.Tp;
+    // softmax backward needs sum_tau attn*dattn over the whole utterance
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < len; i += 256) dot += att[i] * dat[i];
+    dot = block_sum(dot, s4);
+    if (threadIdx.x < TT) {
+        const int tau = tau0 + threadIdx.x;
+        s_de[threadIdx.x] = (tau < len) ? att[tau] * (dat[tau] - dot) / d.temperature : 0.f;
+    }
+    for (int i = threadIdx.x; i < d.A * (1 + d.Kn); i += 256) s_part[i] = 0.f;
+    __syncthreads();
+
+    const float* qrow = p.f.s.q + ((long)b * d.L + t) * d.A;
+    float* dqrow = p.dq + ((long)b * d.L + t) * d.A;
+    for (int a = lane; a < d.A; a += 64) {
+        float wp[KNMAX], dwp[KNMAX];
+#pragma unroll
+        for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? p.f.w.Wproj[(long)a * d.Kn + k] : 0.f; dwp[k] = 0.f; }
+        const float qa = qrow[a], wga = p.f.w.wg[a];
+        float dwg = 0.f, dqa = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int ti = wave * 16 + i;
+            const int tau = tau0 + ti;
+            float dl = 0.f;
+            if (tau < len) {
+                float lp = 0.f;
+#pragma unroll
+                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
+                const float loc = tanhf(lp);
+                const long ki = ((long)b * d.Tp + tau) * d.A + a;
+                const float u = tanhf(p.f.s.key[ki] + qa + loc);
+                const float de = s_de[ti];
+                const float du = de * wga * (1.f - u * u);
+                dwg += de * u;
+                dqa += du;
+                p.dkey[ki] += du;
+                dl = du * (1.f - loc * loc);
+#pragma unroll
+                for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + ti];
+            }
+            s_dl[ti * AP + a] = dl;
+        }
+        atomicAdd(&s_part[a], dwg);
+#pragma unroll
+        for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) atomicAdd(&s_part[d.A + a * d.Kn + k], dwp[k]);
+        atomicAdd(&dqrow[a], dqa);
+    }
+    __syncthreads();
+    // dconv[tau,k] = sum_a dl[tau,a] * Wproj[a,k]
+    for (int o = threadIdx.x; o < d.Kn * TT; o += 256) {
+        const int ti = o % TT, k = o / TT;
+        const int tau = tau0 + ti;
+        float acc = 0.f;
+        if (tau < len) for (int a = 0; a < d.A; ++a) acc += s_dl[ti * AP + a] * p.f.w.Wproj[(long)a * d.Kn + k];
+        if (tau < d.Tp) p.dconv[((long)b * d.Kn + k) * d.Tp + tau] = acc;
+    }
+    // per-workgroup partial sums, accumulated across steps in this workgroup's private slot
+    float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot;
+    for (int i = threadIdx.x; i < d.A * (1 + d.Kn); i += 256) slot[i] += s_part[i];
+    float sde = (threadIdx.x < TT) ? s_de[threadIdx.x] : 0.f;
+    sde = block_sum(sde, s4);
+    if (threadIdx.x == 0) slot[d.A * (1 + d.Kn)] += sde;
+}
+
+// B2c: gradient through the location convolution: datt_next (wrt attn_{t-1}) and d W_conv partials
+__global__ __launch_bounds__(256) void att_bwd_conv_kernel(DecB p, int t) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const asr_dec_dims_t& d = p.f.d;
+    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
+    const int taps = 2 * d.Ks + 1, win = TT + 2 * d.Ks;
+    const int len = min((int)p.f.enc_len[b], d.Tp);
+    float* s_wc = smem_f;                    // [Kn*taps]
+    float* s_dc = s_wc + d.Kn * taps;        // [Kn*win]  dconv window tau0-Ks .. tau0+TT+Ks
+    float* s_pa = s_dc + d.Kn * win;         // [win]     prev_att window (for d W_conv)
+    for (int i = threadIdx.x; i < d.Kn * taps; i += 256) s_wc[i] = p.f.w.Wconv[i];
+    for (int i = threadIdx.x; i < d.Kn * win; i += 256) {
+        const int k = i / win, tau = tau0 + (i % win) - d.Ks;
+        s_dc[i] = (tau >= 0 && tau < d.Tp) ? p.dconv[((long)b * d.Kn + k) * d.Tp + tau] : 0.f;
+    }
+    const float* prev = (t > 0) ? p.f.s.att + ((long)b * d.L + (t - 1)) * d.Tp : nullptr;
+    for (int i = threadIdx.x; i < win; i += 256) {
+        const int tau = tau0 + i - d.Ks;
+        float v = 0.f;
+        if (tau >= 0 && tau < d.Tp) v = prev ? prev[tau] : (tau < len ? 1.f / (float)len : 0.f);
+        s_pa[i] = v;
+    }
+    __syncthreads();
+    // conv[k][tau] = sum_j W[k][j] pa[tau + j - Ks]  =>  d pa[tau'] = sum_k sum_j W[k][j] dconv[k][tau' - j + Ks]
+    if (t > 0 && threadIdx.x < TT) {
+        const int i = threadIdx.x, tau = tau0 + i;
+        if (tau < d.Tp) {
+            float acc = 0.f;
+            for (int k = 0; k < d.Kn; ++k) {
+                const float* wk = s_wc + k * taps;
+                const float* dc = s_dc + k * win + i + 2 * d.Ks;   // index of tau' + Ks  (window offset Ks)
+                for (int j = 0; j < taps; ++j) acc += wk[j] * dc[-j];
+            }
+            p.datt_next[(long)b * d.Tp + tau] = acc;
+        }
+    }
+    // d W_conv[k][j] += sum_{tau in tile} dconv[k][tau] * pa[tau + j - Ks]
+    float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot + d.A * (1 + d.Kn) + 1;
+    for (int o = threadIdx.x; o < d.Kn * taps; o += 256) {
+        const int k = o / taps, j = o % taps;
+        float acc = 0.f;
+        for (int i = 0; i < TT; ++i) acc += s_dc[k * win + d.Ks + i] * s_pa[i + j];
+        slot[o] += acc;
+    }
+}
+
+// B3: query backward.  dq[b,t,:] <- dq * (1 - q^2);  dhs[b,t-1,:] += that * W_q   (one wave per 16 columns of Q)
+template <bool BF16>
+__global__ __launch_bounds__(64) void dec_query_bwd_kernel(DecB p, int t) {
+    const asr_dec_dims_t& d = p.f.d;
+    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+    const int c = blockIdx.x * 16 + n;
+    const bool cok = c < d.Q;
+    const float* wrow = p.wqT + (long)(cok ? c : 0) * d.A;
+    for (int m0 = 0; m0 < d.B; m0 += 16) {
+        const int ab = m0 + n;
+        const bool rok = ab < d.B;
+        const float* drow = p.dq + ((long)(rok ? ab : 0) * d.L + t) * d.A;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = dot_rows<BF16>(drow, rok, wrow, cok, d.A, 0, 1, (d.A % 4) == 0, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = m0 + 4 * q + r;
+            if (cok && b < d.B) p.dhs[((long)b * d.L + (t - 1)) * d.Q + c] += acc[r];
+        }
+    }
+}
+__global__ void dq_pre_kernel(DecB p, int t) {
+    const asr_dec_dims_t& d = p.f.d;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.B * d.A) return;
+    const long idx = ((long)(i / d.A) * d.L + t) * d.A + (i % d.A);
+    const float qv = p.f.s.q[idx];
+    p.dq[idx] *= (1.f - qv * qv);
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, long ld_dst, long col0) {
+    // src (R x C) -> dst[(c + 0) * ld_dst + col0 + r]
+    const long total = (long)R * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i % C);
+        dst[(long)c * ld_dst + col0 + r] = src[i];
+    }
+}
+
+// reduce the per-workgroup slots into the parameter gradients
+__global__ void slot_reduce_kernel(const float* __restrict__ slots, int nslots, int slot, float* __restrict__ out, int off, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int s = 0; s < nslots; ++s) acc += slots[(long)s * slot + off + i];
+    out[i] += acc;
+}
+
+// embedding gradient: dE[v,:] += sum over (b,t) with tokens[b,t] == v of dxin[b,t,0:Dd]   (deterministic)
+__global__ void embed_bwd_kernel(const float* __restrict__ dxin, const int64_t* __restrict__ tokens, float* __restrict__ demb,
+                                 int B, int L, int Dd, int XW, int V) {
+    const int v = blockIdx.x;
+    for (int k = threadIdx.x; k < Dd; k += blockDim.x) {
+        float acc = 0.f;
+        for (int i = 0; i < B * L; ++i)
+            if (tokens[i] == v) acc += dxin[(long)i * XW + k];
+        demb[(long)v * Dd + k] += acc;
+    }
+}
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct BwdLayout {
+    size_t dhs, dxin, dq, dkey, dattn, datt_next, dconv, dcf, wq_t, slots, dkeypre, wcat[ASR_MAX_DEC_LAYERS], total;
+    int ntiles, slot;
+};
+BwdLayout bwd_layout(const asr_dec_dims_t& d) {
+    BwdLayout o;
+    size_t off = 0;
+    auto take = [&](size_t nfloat) { size_t r = off; off += align_up(nfloat * sizeof(float)); return r; };
+    const int XW = d.Dd + d.E;
+    o.ntiles = cdiv(d.Tp, TT);
+    o.slot = d.A * (1 + d.Kn) + 1 + d.Kn * (2 * d.Ks + 1);
+    o.dhs = take((size_t)d.B * d.L * d.NL * d.Dd);
+    o.dxin = take((size_t)d.B * d.L * XW);
+    o.dq = take((size_t)d.B * d.L * d.A);
+    o.dkey = take((size_t)d.B * d.Tp * d.A);
+    o.dkeypre = take((size_t)d.B * d.Tp * d.A);
+    o.dattn = take((size_t)d.B * d.Tp);
+    o.datt_next = take((size_t)d.B * d.Tp);
+    o.dconv = take((size_t)d.B * d.Kn * d.Tp);
+    o.dcf = take((size_t)d.NL * d.B * d.Dd);
+    o.wq_t = take((size_t)d.Q * d.A);
+    o.slots = take((size_t)d.B * o.ntiles * o.slot);
+    for (int l = 0; l < d.NL; ++l) o.wcat[l] = take((size_t)((l == 0 ? XW : d.Dd) + d.Dd) * 4 * d.Dd);
+    o.total = off;
+    return o;
+}
+
+int check_dims(const asr_dec_dims_t& d, const char* who) {
+    ASR_REQUIRE(d.B > 0 && d.Tp > 0 && d.E > 0 && d.A > 0 && d.Dd > 0 && d.V > 1 && d.L > 0, ASR_E_ARG, "%s: bad dims", who);
+    ASR_REQUIRE(d.NL >= 1 && d.NL <= ASR_MAX_DEC_LAYERS, ASR_E_UNSUPPORTED, "%s: %d decoder layers (max %d)", who, d.NL, ASR_MAX_DEC_LAYERS);
+    ASR_REQUIRE(d.Q == d.Dd * d.NL, ASR_E_ARG, "%s: Q must equal Dd*NL", who);
+    ASR_REQUIRE(d.Kn >= 1 && d.Kn <= 16, ASR_E_UNSUPPORTED, "%s: loc_kernel_num %d not in [1,16]", who, d.Kn);
+    ASR_REQUIRE(d.Ks >= 0 && d.Ks <= 512, ASR_E_UNSUPPORTED, "%s: loc_kernel_size %d too large", who, d.Ks);
+    ASR_REQUIRE(d.temperature > 0.f, ASR_E_ARG, "%s: temperature must be > 0", who);
+    ASR_REQUIRE(d.Tp <= 12000, ASR_E_UNSUPPORTED, "%s: T'=%d exceeds the LDS row budget", who, d.Tp);
+    return ASR_OK;
+}
+
+}  // namespace
+
+extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights,
+                                   const float* enc, const int64_t* enc_len, const int64_t* teacher, int teacher_ld,
+                                   const asr_dec_state_t* state, int prec, asr_stream_t stream) {
+    ASR_REQUIRE(dims && weights && enc && enc_len && state, ASR_E_ARG, "asr_att_decoder_fwd: null pointer");
+    const asr_dec_dims_t& d = *dims;
+    int rc = check_dims(d, "asr_att_decoder_fwd");
+    if (rc != ASR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    DecP p{d, *weights, *state, enc, enc_len};
+    const int XW = d.Dd + d.E;
+    const bool bf = (prec == ASR_BF16);
+
+    // key = tanh(enc W_k^T + b_k), once per batch (src/asr.py:345)
+    rc = asr_gemm(enc, weights->Wk, state->key, weights->bk, d.B * d.Tp, d.A, d.E, d.E, d.E, d.A, 1, 1, ASR_ACT_TANH, 0, 1,
+                  1, 0, 0, 0, 0, 0, prec, stream);
+    if (rc != ASR_OK) return rc;
+
+    if (teacher) {
+        hipLaunchKernelGGL(shift_tokens_kernel, dim3(cdiv(d.B * d.L, 256)), dim3(256), 0, st, teacher, state->tokens, d.B, d.L, teacher_ld);
+        hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.L * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens,
+                           state->xin, d.B, d.L, d.Dd, XW, 0, d.L, d.V);
+    } else {
+        hipMemsetAsync(state->tokens, 0, sizeof(int64_t) * d.B * d.L, st);
+    }
+
+    const int taps = 2 * d.Ks + 1;
+    const size_t lds_energy = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT);
+    const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
+    for (int t = 0; t < d.L; ++t) {
+        if (!teacher)
+            hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens,
+                               state->xin, d.B, d.L, d.Dd, XW, t, 1, d.V);
+        if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
+        else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
+        if (d.Kn <= 4)       hipLaunchKernelGGL(att_energy_kernel<4>, grid_tile, dim3(256), lds_energy, st, p, t);
+        else if (d.Kn <= 10) hipLaunchKernelGGL(att_energy_kernel<10>, grid_tile, dim3(256), lds_energy, st, p, t);
+        else                 hipLaunchKernelGGL(att_energy_kernel<16>, grid_tile, dim3(256), lds_energy, st, p, t);
+        hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
+        for (int l = 0; l < d.NL; ++l) {
+            if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(64), 0, st, p, t, l);
+            else    hipLaunchKernelGGL(dec_cell_fwd_kernel<false>, dim3(cdiv(d.Dd, 4)), dim3(64), 0, st, p, t, l);
+        }
+        if (!teacher) hipLaunchKernelGGL(dec_greedy_kernel, dim3(d.B), dim3(256), sizeof(float) * d.V, st, p, t);
+    }
+    ASR_LAUNCH_CHECK("asr_att_decoder_fwd");
+    if (teacher) {
+        // logits[b,t,:] = W_c h_top[b,t] + b_c for all steps in one contraction
+        rc = asr_gemm(state->hs + (size_t)(d.NL - 1) * d.Dd, weights->Wc, state->logits, weights->bc, d.B * d.L, d.V, d.Dd,
+                      (long)d.NL * d.Dd, d.Dd, d.V, 1, 1, ASR_ACT_NONE, 0, 1, 1, 0, 0, 0, 0, 0, prec, stream);
+        if (rc != ASR_OK) return rc;
+    }
+    return ASR_OK;
+}
+
+extern "C" size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims) {
+    if (!dims) return 0;
+    return bwd_layout(*dims).total;
+}
+
+extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights, const asr_dec_grads_t* grads,
+                                   const float* enc, const int64_t* enc_len, const asr_dec_state_t* state,
+                                   const float* dlogits, float* denc,
+                                   void* workspace, size_t workspace_bytes, int prec, asr_stream_t stream) {
+    ASR_REQUIRE(dims && weights && grads && enc && enc_len && state && dlogits && denc && workspace, ASR_E_ARG,
+                "asr_att_decoder_bwd: null pointer");
+    const asr_dec_dims_t& d = *dims;
+    int rc = check_dims(d, "asr_att_decoder_bwd");
+    if (rc != ASR_OK) return rc;
+    const BwdLayout lay = bwd_layout(d);
+    ASR_REQUIRE(workspace_bytes >= lay.total, ASR_E_ARG, "asr_att_decoder_bwd: workspace %zu < %zu", workspace_bytes, lay.total);
+    ASR_REQUIRE(((uintptr_t)workspace & 255) == 0, ASR_E_ARG, "asr_att_decoder_bwd: workspace must be 256B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int XW = d.Dd + d.E;
+    const bool bf = (prec == ASR_BF16);
+    const long SW = (long)d.NL * d.Dd;
+    const int BL = d.B * d.L;
+
+    DecB p;
+    p.f = DecP{d, *weights, *state, enc, enc_len};
+    p.g = *grads;
+    p.dhs = (float*)(ws + lay.dhs); p.dxin = (float*)(ws + lay.dxin); p.dq = (float*)(ws + lay.dq);
+    p.dkey = (float*)(ws + lay.dkey); p.dattn = (float*)(ws + lay.dattn); p.datt_next = (float*)(ws + lay.datt_next);
+    p.dconv = (float*)(ws + lay.dconv); p.dcf = (float*)(ws + lay.dcf); p.wqT = (float*)(ws + lay.wq_t);
+    p.slots = (float*)(ws + lay.slots); p.ntiles = lay.ntiles; p.slot = lay.slot;
+    float* dkeypre = (float*)(ws + lay.dkeypre);
+    for (int l = 0; l < ASR_MAX_DEC_LAYERS; ++l) p.wcatT[l] = (l < d.NL) ? (float*)(ws + lay.wcat[l]) : nullptr;
+
+    // zero-initialised accumulators: dhs, dq, dkey, slots  (dxin is fully written by the loop)
+    hipMemsetAsync(p.dhs, 0, sizeof(float) * (size_t)BL * SW, st);
+    hipMemsetAsync(p.dq, 0, sizeof(float) * (size_t)BL * d.A, st);
+    hipMemsetAsync(p.dkey, 0, sizeof(float) * (size_t)d.B * d.Tp * d.A, st);
+    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * lay.ntiles * lay.slot, st);
+
+    // transposed weights so that every per-step contraction is K-contiguous
+    for (int l = 0; l < d.NL; ++l) {
+        const int Kx = (l == 0) ? XW : d.Dd;
+        hipLaunchKernelGGL(transpose_kernel, dim3(256), dim3(256), 0, st, weights->Wih[l], p.wcatT[l], 4 * d.Dd, Kx, (long)4 * d.Dd, 0L);
+        // rows Kx.. of wcatT hold W_hh^T
+        hipLaunchKernelGGL(transpose_kernel, dim3(256), dim3(256), 0, st, weights->Whh[l], p.wcatT[l] + (size_t)Kx * 4 * d.Dd, 4 * d.Dd, d.Dd,
+                           (long)4 * d.Dd, 0L);
+    }
+    hipLaunchKernelGGL(transpose_kernel, dim3(256), dim3(256), 0, st, weights->Wq, p.wqT, d.A, d.Q, (long)d.A, 0L);
+
+    // output layer: dh_top = dlogits W_c ; dW_c += dlogits^T h_top ; db_c += colsum(dlogits)
+    rc = asr_gemm(dlogits, weights->Wc, p.dhs + (size_t)(d.NL - 1) * d.Dd, nullptr, BL, d.Dd, d.V, d.V, d.Dd, SW, 1, 0,
+                  ASR_ACT_NONE, 0, 1, 1, 0, 0, 0, 0, 0, prec, stream);
+    if (rc != ASR_OK) return rc;
+    rc = asr_gemm(dlogits, state->hs + (size_t)(d.NL - 1) * d.Dd, grads->Wc, nullptr, d.V, d.Dd, BL, d.V, SW, d.Dd, 0, 0,
+                  ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, 0, 0, prec, stream);
+    if (rc != ASR_OK) return rc;
+    rc = asr_colsum(dlogits, d.V, BL, d.V, grads->bc, stream);
+    if (rc != ASR_OK) return rc;
+
+    const int taps = 2 * d.Ks + 1;
+    const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
+    const size_t lds_e = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT + (size_t)d.A * (1 + d.Kn) +
+                                          (size_t)TT * (d.A | 1));
+    const size_t lds_c = sizeof(float) * ((size_t)d.Kn * taps + (size_t)(d.Kn + 1) * (TT + 2 * d.Ks));
+    ASR_REQUIRE(lds_e <= 160 * 1024 - 1024, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: attention dim %d needs %zu B of LDS", d.A, lds_e);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        attr_set = true;
+    }
+
+    for (int t = d.L - 1; t >= 0; --t) {
+        const int last = (t == d.L - 1);
+        for (int l = d.NL - 1; l >= 0; --l) {
+            hipLaunchKernelGGL(dec_cell_bwd_elem_kernel, dim3(cdiv(d.B * d.Dd, 256)), dim3(256), 0, st, p, t, l, last);
+            const int width = ((l == 0) ? XW : d.Dd) + d.Dd;
+            if (bf) hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<true>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
+            else    hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<false>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
+        }
+        hipLaunchKernelGGL(att_bwd_dattn_kernel, grid_tile, dim3(256), sizeof(float) * d.E, st, p, t, last);
+        if (d.Kn <= 4)       hipLaunchKernelGGL(att_bwd_energy_kernel<4>, grid_tile, dim3(256), lds_e, st, p, t);
+        else if (d.Kn <= 10) hipLaunchKernelGGL(att_bwd_energy_kernel<10>, grid_tile, dim3(256), lds_e, st, p, t);
+        else                 hipLaunchKernelGGL(att_bwd_energy_kernel<16>, grid_tile, dim3(256), lds_e, st, p, t);
+        hipLaunchKernelGGL(att_bwd_conv_kernel, grid_tile, dim3(256), lds_c, st, p, t);
+        hipLaunchKernelGGL(dq_pre_kernel, dim3(cdiv(d.B * d.A, 256)), dim3(256), 0, st, p, t);
+        if (t > 0) {
+            if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(64), 0, st, p, t);
+            else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(64), 0, st, p, t);
+        }
+    }
+    ASR_LAUNCH_CHECK("asr_att_decoder_bwd");
+
+    // ---- batched parameter gradients -----------------------------------------------------------
+    for (int l = 0; l < d.NL; ++l) {
+        const float* dg = state->gates + (size_t)l * 4 * d.Dd;   // rows (b,t), stride NL*4Dd
+        const long ldg = (long)d.NL * 4 * d.Dd;
+        const int Kx = (l == 0) ? XW : d.Dd;
+        const float* xl = (l == 0) ? state->xin : state->hs + (size_t)(l - 1) * d.Dd;
+        const long ldx = (l == 0) ? XW : SW;
+        rc = asr_gemm(dg, xl, grads->Wih[l], nullptr, 4 * d.Dd, Kx, BL, ldg, ldx, Kx, 0, 0, ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, 0, 0, prec, stream);
+        if (rc != ASR_OK) return rc;
+        rc = asr_gemm(dg, state->hs + (size_t)l * d.Dd, grads->Whh[l], nullptr, 4 * d.Dd, d.Dd, BL, ldg, SW, d.Dd, 0, 0, ASR_ACT_NONE,
+                      1, 1, 1, 0, 0, 0, d.L, -1, prec, stream);
+        if (rc != ASR_OK) return rc;
+        rc = asr_colsum(dg, ldg, BL, 4 * d.Dd, grads->bih[l], stream);
+        if (rc != ASR_OK) return rc;
+        rc = asr_colsum(dg, ldg, BL, 4 * d.Dd, grads->bhh[l], stream);
+        if (rc != ASR_OK) return rc;
+    }
+    // query projection: dW_q += dqpre^T hcat_{t-1}, db_q += colsum(dqpre)
+    rc = asr_gemm(p.dq, state->hs, grads->Wq, nullptr, d.A, d.Q, BL, d.A, d.Q, d.Q, 0, 0, ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, d.L, -1, prec, stream);
+    if (rc != ASR_OK) return rc;
+    rc = asr_colsum(p.dq, d.A, BL, d.A, grads->bq, stream);
+    if (rc != ASR_OK) return rc;
+    // embedding
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(d.V), dim3(256), 0, st, p.dxin, state->tokens, grads->emb, d.B, d.L, d.Dd, XW, d.V);
+    // context: denc[b] += attn[b]^T (T' x L) dctx[b] (L x E)
+    rc = asr_gemm(state->att, p.dxin + d.Dd, denc, nullptr, d.Tp, d.E, d.L, d.Tp, XW, d.E, 0, 0, ASR_ACT_NONE, 1, 1, d.B,
+                  (long)d.L * d.Tp, (long)d.L * XW, (long)d.Tp * d.E, 0, 0, prec, stream);
+    if (rc != ASR_OK) return rc;
+    // key projection backward
+    rc = asr_act_bwd(p.dkey, state->key, dkeypre, (long)d.B * d.Tp * d.A, ASR_ACT_TANH, stream);
+    if (rc != ASR_OK) return rc;
+    const int M = d.B * d.Tp;
+    const int splits = M >= 4096 ? 8 : 1;
+    rc = asr_gemm(dkeypre, enc, grads->Wk, nullptr, d.A, d.E, M, d.A, d.E, d.E, 0, 0, ASR_ACT_NONE, 1, splits, 1, 0, 0, 0, 0, 0, prec, stream);
+    if (rc != ASR_OK) return rc;
+    rc = asr_colsum(dkeypre, d.A, M, d.A, grads->bk, stream);
+    if (rc != ASR_OK) return rc;
+    rc = asr_gemm(dkeypre, weights->Wk, denc, nullptr, M, d.E, d.A, d.A, d.E, d.E, 1, 0, ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, 0, 0, prec, stream);
+    if (rc != ASR_OK) return rc;
+    // slot partials -> d w_g, d W_proj, d b_g, d W_conv
+    const int nslots = d.B * lay.ntiles;
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A, 256)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->wg, 0, d.A);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A * d.Kn, 256)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wproj, d.A, d.A * d.Kn);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(1), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->bg, d.A * (1 + d.Kn), 1);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.Kn * taps, 256)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wconv,
+                       d.A * (1 + d.Kn) + 1, d.Kn * taps);
+    ASR_LAUNCH_CHECK("asr_att_decoder_bwd(tail)");
+    return ASR_OK;
+}

@@ -1,0 +1,186 @@
+// Time recurrence of the (bi)directional encoder LSTM — the part of nn.LSTM (reference
+// src/module.py:1023,1049) that cannot be batched over time.  The input projections x W_ih^T + b_ih + b_hh
+// for all frames are produced beforehand by asr_gemm into `gates` (B,T,ND,4H); these kernels add
+// h_{t-1} W_hh^T with MFMA (batch rows on the M side, 16 at a time), apply the cell, and overwrite
+// `gates` with the activated (i,f,g,o) that backward needs.  Padded frames are processed like any other
+// frame, exactly as the reference does (it never packs sequences, src/module.py:1047-1054).
+//
+// Launch-per-step form: both directions advance in one launch; h_{t-1} is read straight from the output
+// tensor y and c_{t-1} from the saved cell states, so there is no hidden state besides the outputs.
+#include "common.h"
+
+namespace {
+
+struct LstmP {
+    float* gates;        // (B,T,ND,4H)  in: pre-activations from the input projection; out: activated gates
+    const float* whh;    // fwd: (ND,4H,H) = weight_hh_l0[,_reverse];  bwd: transposed copy (ND,H,4H)
+    float* y;            // (B,T,ND*H)   fwd: h output;  bwd: dy (gradient wrt the LSTM output), read-only
+    float* c;            // (B,T,ND,H)   cell states
+    float* dcf;          // bwd only: (ND,B,H) carry of dc_{t+1} * f_{t+1}
+    const float* bias2;  // fwd only, optional: (ND,4H) second bias (b_hh) added to the pre-activations
+    int B, T, H, ND;
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward step: one wave per (4 hidden units x 4 gates); column n of the MFMA tile = gate n>>2 of
+// hidden unit j0 + (n&3), so the four gates of a unit sit 4 lanes apart and are gathered by shuffles.
+// ---------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(64) void lstm_fwd_step(LstmP p, int s) {
+    const int H = p.H, T = p.T, ND = p.ND;
+    const int d = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int n = lane & 15, q = lane >> 4;
+    const int g = n >> 2;
+    const int j = blockIdx.x * 4 + (n & 3);
+    const bool jok = j < H;
+    const int t = (d == 0) ? s : T - 1 - s;
+    const int tp = (d == 0) ? t - 1 : t + 1;
+    const bool first = (s == 0);
+    const bool vec = (H % 4) == 0;
+    const float* wrow = p.whh + ((long)d * 4 * H + (long)g * H + (jok ? j : 0)) * H;
+    const int base = lane & ~12;
+
+    for (int m0 = 0; m0 < p.B; m0 += 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!first) {
+            const int ab = m0 + n;                       // A row = batch index
+            const bool aok = ab < p.B;
+            const float* hrow = p.y + ((long)(aok ? ab : 0) * T + tp) * ND * H + (long)d * H;
+            acc = dot_rows<BF16>(hrow, aok, wrow, jok, H, 0, 1, vec, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = m0 + 4 * q + r;
+            const bool ok = jok && b < p.B;
+            const long gi = (((long)(ok ? b : 0) * T + t) * ND + d) * 4 * H + (long)g * H + (jok ? j : 0);
+            float pre = ok ? (p.gates[gi] + acc[r] + (p.bias2 ? p.bias2[(long)d * 4 * H + (long)g * H + j] : 0.f)) : 0.f;
+            float a = (g == 2) ? tanhf(pre) : sigmoidf_(pre);
+            if (ok) p.gates[gi] = a;
+            float ai = __shfl(a, base);
+            float af = __shfl(a, base + 4);
+            float ag = __shfl(a, base + 8);
+            float ao = __shfl(a, base + 12);
+            if (ok && g == 0) {
+                float cp = first ? 0.f : p.c[(((long)b * T + tp) * ND + d) * H + j];
+                float cn = af * cp + ai * ag;
+                p.c[(((long)b * T + t) * ND + d) * H + j] = cn;
+                p.y[((long)b * T + t) * ND * H + (long)d * H + j] = ao * tanhf(cn);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward step (BPTT): block = 4 waves x 16 hidden units.  dh_rec = dgates_{next} (B x 4H) * W_hh
+// restricted to the block's 16 columns, reduction over 4H split across the 4 waves and summed in LDS.
+// p.whh is the transposed copy (ND,H,4H) so that every MFMA operand is K-contiguous.
+// ---------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void lstm_bwd_step(LstmP p, int s) {
+    __shared__ float red[4][256];
+    const int H = p.H, T = p.T, ND = p.ND;
+    const int d = blockIdx.y;
+    const int j0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    // backward walks time in the opposite order of the forward pass of that direction
+    const int t = (d == 0) ? T - 1 - s : s;
+    const int tn = (d == 0) ? t + 1 : t - 1;     // step processed just before this one (source of dgates)
+    const int tp = (d == 0) ? t - 1 : t + 1;     // forward-previous step (source of c_{t-1})
+    const bool has_cprev = (d == 0) ? (t > 0) : (t < T - 1);
+    const bool first = (s == 0);
+    const bool vec = (H % 4) == 0;
+    const int K = 4 * H;
+    const bool jok_b = (j0 + n) < H;
+    const float* wrow = p.whh + ((long)d * H + (jok_b ? j0 + n : 0)) * K;
+
+    for (int m0 = 0; m0 < p.B; m0 += 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!first) {
+            const int ab = m0 + n;
+            const bool aok = ab < p.B;
+            const float* grow = p.gates + (((long)(aok ? ab : 0) * T + tn) * ND + d) * K;
+            acc = dot_rows<BF16>(grow, aok, wrow, jok_b, K, wave, 4, vec, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
+        __syncthreads();
+        {
+            const int row = tid >> 4, col = tid & 15;
+            const int b = m0 + row, j = j0 + col;
+            if (b < p.B && j < H) {
+                float dh = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+                dh += p.y[((long)b * T + t) * ND * H + (long)d * H + j];
+                const long gi = (((long)b * T + t) * ND + d) * K + j;
+                const float gi_ = p.gates[gi], gf = p.gates[gi + H], gg = p.gates[gi + 2 * H], go = p.gates[gi + 3 * H];
+                const float ct = p.c[(((long)b * T + t) * ND + d) * H + j];
+                const float cp = has_cprev ? p.c[(((long)b * T + tp) * ND + d) * H + j] : 0.f;
+                const long ci = ((long)d * p.B + b) * H + j;
+                const float carry = first ? 0.f : p.dcf[ci];
+                const float tc = tanhf(ct);
+                const float dc = dh * go * (1.f - tc * tc) + carry;
+                p.gates[gi]         = dc * gg * gi_ * (1.f - gi_);
+                p.gates[gi + H]     = dc * cp * gf * (1.f - gf);
+                p.gates[gi + 2 * H] = dc * gi_ * (1.f - gg * gg);
+                p.gates[gi + 3 * H] = dh * tc * go * (1.f - go);
+                p.dcf[ci] = dc * gf;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void transpose_whh_kernel(const float* __restrict__ w, float* __restrict__ wt, int ND, int H) {
+    // w: (ND,4H,H) -> wt: (ND,H,4H)
+    const long total = (long)ND * 4 * H * H;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % (4 * H));
+        const int j = (int)((i / (4 * H)) % H);
+        const int d = (int)(i / ((long)4 * H * H));
+        wt[i] = w[((long)d * 4 * H + k) * H + j];
+    }
+}
+
+}  // namespace
+
+extern "C" int asr_lstm_fwd(float* gates, const float* whh, const float* bias2, float* y, float* c,
+                            int B, int T, int H, int ND, int prec, asr_stream_t stream) {
+    ASR_REQUIRE(gates && whh && y && c, ASR_E_ARG, "asr_lstm_fwd: null pointer");
+    ASR_REQUIRE(B > 0 && T > 0 && H > 0 && (ND == 1 || ND == 2), ASR_E_ARG, "asr_lstm_fwd: bad dims");
+    ASR_REQUIRE(((uintptr_t)whh & 15) == 0 && ((uintptr_t)y & 15) == 0, ASR_E_ARG, "asr_lstm_fwd: unaligned");
+    LstmP p{gates, whh, y, c, nullptr, bias2, B, T, H, ND};
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cdiv(H, 4), ND), block(64);
+    for (int s = 0; s < T; ++s) {
+        if (prec == ASR_BF16) hipLaunchKernelGGL(lstm_fwd_step<true>, grid, block, 0, st, p, s);
+        else                  hipLaunchKernelGGL(lstm_fwd_step<false>, grid, block, 0, st, p, s);
+    }
+    ASR_LAUNCH_CHECK("asr_lstm_fwd");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_lstm_bwd_workspace_bytes(int B, int H, int ND) {
+    return ((size_t)ND * H * 4 * H + (size_t)ND * B * H) * sizeof(float);
+}
+
+extern "C" int asr_lstm_bwd(float* gates, const float* whh, const float* dy, const float* c,
+                            int B, int T, int H, int ND, int prec,
+                            void* workspace, size_t workspace_bytes, asr_stream_t stream) {
+    ASR_REQUIRE(gates && whh && dy && c && workspace, ASR_E_ARG, "asr_lstm_bwd: null pointer");
+    ASR_REQUIRE(B > 0 && T > 0 && H > 0 && (ND == 1 || ND == 2), ASR_E_ARG, "asr_lstm_bwd: bad dims");
+    ASR_REQUIRE(workspace_bytes >= asr_lstm_bwd_workspace_bytes(B, H, ND), ASR_E_ARG, "asr_lstm_bwd: workspace too small");
+    ASR_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)gates & 15) == 0, ASR_E_ARG, "asr_lstm_bwd: unaligned");
+    hipStream_t st = (hipStream_t)stream;
+    float* wt = (float*)workspace;
+    float* dcf = wt + (size_t)ND * H * 4 * H;
+    hipLaunchKernelGGL(transpose_whh_kernel, dim3(256), dim3(256), 0, st, whh, wt, ND, H);
+    LstmP p{gates, wt, const_cast<float*>(dy), const_cast<float*>(c), dcf, nullptr, B, T, H, ND};
+    dim3 grid(cdiv(H, 16), ND), block(256);
+    for (int s = 0; s < T; ++s) {
+        if (prec == ASR_BF16) hipLaunchKernelGGL(lstm_bwd_step<true>, grid, block, 0, st, p, s);
+        else                  hipLaunchKernelGGL(lstm_bwd_step<false>, grid, block, 0, st, p, s);
+    }
+    ASR_LAUNCH_CHECK("asr_lstm_bwd");
+    return ASR_OK;
+}

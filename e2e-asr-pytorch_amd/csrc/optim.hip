@@ -1,0 +1,90 @@
+// Post-backward step on the flat parameter / gradient buffers (all parameters of the model live in one
+// contiguous fp32 buffer, gradients in another — also the RCCL all-reduce bucket):
+//   asr_sumsq        : sum of squares (for the global L2 norm of clip_grad_norm_, src/solver.py:97)
+//   asr_scale        : in-place scale (averaging after the gradient all-reduce)
+//   asr_adadelta_step: clip-by-global-norm + NaN guard + torch.optim.Adadelta update fused, reading the
+//                      squared norm from device memory so the host never synchronises
+//                      (src/solver.py:96-103 + src/optim.py:29,53-54)
+// Pure HBM streaming: 12-19 M parameters, 4 tensors read + 3 written per step.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, double* __restrict__ out) {
+    __shared__ double s4[4];
+    double acc = 0.0;
+    const long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[(n4 << 2) + threadIdx.x]; acc += (double)v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, s4[0] + s4[1] + s4[2] + s4[3]);
+}
+
+__global__ void scale_kernel(float* x, long n, float k) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= k;
+}
+
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ sq, float* __restrict__ ad, long n,
+                                                       float lr, float rho, float eps, float wd, float clip,
+                                                       const double* __restrict__ normsq, float gmul) {
+    // gmul: extra factor applied to the stored gradient before clipping (1/world_size when the buffer holds a sum)
+    float coef = gmul;
+    if (normsq) {
+        const double nrm = sqrt(*normsq) * (double)gmul;
+        if (!(nrm == nrm) || nrm == INFINITY) return;      // NaN/inf gradient norm: skip the update (src/solver.py:99-103)
+        if (clip > 0.f) {
+            const double c = (double)clip / (nrm + 1e-6);
+            if (c < 1.0) coef *= (float)c;
+        }
+    }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * coef;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float s = rho * sq[i] + (1.f - rho) * gi * gi;
+        const float a = ad[i];
+        const float delta = sqrtf(a + eps) / sqrtf(s + eps) * gi;
+        sq[i] = s;
+        ad[i] = rho * a + (1.f - rho) * delta * delta;
+        p[i] = pi - lr * delta;
+    }
+}
+
+inline int grid_for(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
+
+}  // namespace
+
+extern "C" int asr_sumsq(const float* x, long n, double* out, asr_stream_t stream) {
+    ASR_REQUIRE(x && out && n > 0, ASR_E_ARG, "asr_sumsq: bad args");
+    ASR_REQUIRE(((uintptr_t)x & 15) == 0, ASR_E_ARG, "asr_sumsq: x must be 16B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(out, 0, sizeof(double), st);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, x, n, out);
+    ASR_LAUNCH_CHECK("asr_sumsq");
+    return ASR_OK;
+}
+
+extern "C" int asr_scale(float* x, long n, float k, asr_stream_t stream) {
+    ASR_REQUIRE(x && n > 0, ASR_E_ARG, "asr_scale: bad args");
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, k);
+    ASR_LAUNCH_CHECK("asr_scale");
+    return ASR_OK;
+}
+
+extern "C" int asr_adadelta_step(float* param, const float* grad, float* square_avg, float* acc_delta, long n,
+                                 float lr, float rho, float eps, float weight_decay, float clip,
+                                 const double* normsq, float grad_mul, asr_stream_t stream) {
+    ASR_REQUIRE(param && grad && square_avg && acc_delta && n > 0, ASR_E_ARG, "asr_adadelta_step: bad args");
+    hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, square_avg,
+                       acc_delta, n, lr, rho, eps, weight_decay, clip, normsq, grad_mul);
+    ASR_LAUNCH_CHECK("asr_adadelta_step");
+    return ASR_OK;
+}

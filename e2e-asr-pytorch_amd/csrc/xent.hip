@@ -1,0 +1,76 @@
+// Token-level sequence losses of the attention decoder, forward + gradient in one pass:
+//   mode 0: torch.nn.CrossEntropyLoss(ignore_index=0)  — mean over non-pad targets (bin/train_asr.py:134,245)
+//   mode 1: LabelSmoothingLoss(classes, smoothing)     — mean over ALL rows, pad rows included, target
+//           distribution 1-s on the label and s/(classes-1) elsewhere (src/util.py:11-25; the Solver
+//           hard-codes classes=31, bin/train_asr.py:131)
+// One wave per row (V <= a few thousand), fp32 log-softmax.
+#include "common.h"
+
+namespace {
+
+struct XentP {
+    const float* logits; const int64_t* tgt; long tgt_ld; int L;   // row r = b*L + t  ->  tgt[b*tgt_ld + t]
+    float* dlogits; float* accum;   // accum[0] = sum of row losses, accum[1] = number of counted rows
+    long R; int V; int mode; int classes; float smoothing;
+};
+
+__global__ __launch_bounds__(256) void xent_rows_kernel(XentP p) {
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= p.R) return;
+    const float* x = p.logits + row * p.V;
+    float* dx = p.dlogits + row * p.V;
+    long tg = p.tgt[(row / p.L) * p.tgt_ld + (row % p.L)];
+    float m = -INFINITY;
+    for (int v = lane; v < p.V; v += 64) m = fmaxf(m, x[v]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int v = lane; v < p.V; v += 64) s += expf(x[v] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    if (p.mode == 0) {
+        const bool counted = (tg != 0) && tg >= 0 && tg < p.V;
+        for (int v = lane; v < p.V; v += 64) dx[v] = counted ? (expf(x[v] - lse) - (v == tg ? 1.f : 0.f)) : 0.f;
+        if (lane == 0 && counted) { atomicAdd(&p.accum[0], lse - x[tg]); atomicAdd(&p.accum[1], 1.f); }
+    } else {
+        const float off = p.smoothing / (float)(p.classes - 1), conf = 1.f - p.smoothing;
+        float loss = 0.f;
+        const float tot = conf + off * (float)(p.V - 1);
+        for (int v = lane; v < p.V; v += 64) {
+            const float lp = x[v] - lse;
+            const float tv = (v == tg) ? conf : off;
+            loss -= tv * lp;
+            dx[v] = tot * expf(lp) - tv;
+        }
+        loss = wave_sum(loss);
+        if (lane == 0) { atomicAdd(&p.accum[0], loss); atomicAdd(&p.accum[1], 1.f); }
+    }
+}
+
+// loss = accum[0]/accum[1];  dlogits *= gscale/accum[1]
+__global__ void xent_finish_kernel(float* dlogits, long n, const float* accum, float* loss, float gscale) {
+    const float cnt = accum[1];
+    const float k = gscale / cnt;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dlogits[i] *= k;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *loss = accum[0] / cnt;
+}
+
+}  // namespace
+
+extern "C" int asr_xent(const float* logits, const int64_t* targets, long target_ld, float* dlogits, float* loss,
+                        float* accum2, int B, int L, int V, int mode, int classes, float smoothing, float gscale,
+                        asr_stream_t stream) {
+    ASR_REQUIRE(logits && targets && dlogits && loss && accum2, ASR_E_ARG, "asr_xent: null pointer");
+    ASR_REQUIRE(B > 0 && L > 0 && V > 1 && target_ld >= L, ASR_E_ARG, "asr_xent: bad dims");
+    ASR_REQUIRE(mode == 0 || (mode == 1 && classes > 1), ASR_E_ARG, "asr_xent: bad mode");
+    hipStream_t st = (hipStream_t)stream;
+    const long R = (long)B * L;
+    XentP p{logits, targets, target_ld, L, dlogits, accum2, R, V, mode, classes, smoothing};
+    hipMemsetAsync(accum2, 0, 2 * sizeof(float), st);
+    hipLaunchKernelGGL(xent_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, p);
+    const long n = R * V;
+    long g = (n + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(xent_finish_kernel, dim3((int)g), dim3(256), 0, st, dlogits, n, accum2, loss, gscale);
+    ASR_LAUNCH_CHECK("asr_xent");
+    return ASR_OK;
+}

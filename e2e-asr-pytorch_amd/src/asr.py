@@ -1,0 +1,243 @@
+"""Joint CTC-attention ASR model on the MI355X HIP path.
+
+Drop-in for the reference's `src/asr.ASR` (constructor kwargs = the YAML `model:` block, same
+`forward` signature and return tuple, same attribute and state_dict names: reference src/asr.py:13-177),
+but every tensor operation on the path runs in libasr_hip.so.  The nn.Modules only hold parameters, which
+all live in ONE flat fp32 buffer (plus one flat gradient buffer = the data-parallel all-reduce bucket).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from src import functions as F_hip
+from src import hipabi as H
+from src.module import RNNLayer, Downsampler, LocationAwareAttention, LSTMParams
+from src.util import init_weights_, init_gate_
+
+ALIGN = 64  # floats; every parameter group starts on a 256-byte boundary of the flat buffer
+
+
+class _RunCtx(object):
+    """Per-forward bookkeeping handed to the layers: autograd anchor, precision, dropout seeds."""
+
+    def __init__(self, model):
+        self.anchor = model._anchor
+        self.prec = model.prec
+        self._model = model
+
+    def next_seed(self):
+        self._model._drop_counter += 1
+        return (self._model.seed * 1000003 + self._model._drop_counter) & 0xFFFFFFFFFFFF
+
+
+class Encoder(nn.Module):
+    """Listener: optional VGG / down-sampler front-end + stacked (pyramidal) BiLSTM layers
+    (reference src/asr.py:390-476)."""
+
+    def __init__(self, input_size, batch_size, vgg, vgg_freq, vgg_low_filt, module, bidirection, dim, dropout,
+                 layer_norm, proj, sample_rate, sample_style):
+        super().__init__()
+        self.vgg, self.vgg_freq, self.vgg_low_filt = vgg, vgg_freq, vgg_low_filt
+        self.sample_rate = 1
+        assert len(sample_rate) == len(dropout), 'Number of layer mismatch'
+        assert len(dropout) == len(dim), 'Number of layer mismatch'
+        layers = []
+        input_dim = input_size
+        if vgg > 0:
+            if vgg == 1:
+                from src.vgg import VGGExtractor
+                ext = VGGExtractor(input_size)
+            elif vgg == 5:
+                from src.vgg import VGGExtractor_LN
+                ext = VGGExtractor_LN(input_size)
+            elif vgg == 6:
+                ext = Downsampler(input_size)
+            else:
+                raise NotImplementedError('vgg = {} is not available on the HIP path'.format(vgg))
+            layers.append(ext)
+            input_dim = ext.out_dim
+            self.sample_rate = self.sample_rate * (4 if (vgg < 3 or vgg == 6) else 2)
+        if module not in ('LSTM',):
+            raise NotImplementedError('encoder module %s is not available on the HIP path' % module)
+        for l in range(len(dim)):
+            layers.append(RNNLayer(input_dim, module, dim[l], bidirection, dropout[l], layer_norm[l], sample_rate[l],
+                                   sample_style, proj[l], batch_size))
+            input_dim = layers[-1].out_dim
+            self.sample_rate = self.sample_rate * sample_rate[l]
+        self.in_dim, self.out_dim = input_size, input_dim
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, input_x, enc_len, ctx=None):
+        for layer in self.layers:
+            input_x, enc_len = layer(input_x, enc_len, ctx)
+        return input_x, enc_len
+
+
+class Decoder(nn.Module):
+    """Speller parameters: `layers` (LSTM weights), `char_trans` (reference src/asr.py:183-270)."""
+
+    def __init__(self, batch_size, input_dim, vocab_size, module, dim, layer, dropout):
+        super().__init__()
+        if module != 'LSTM':
+            raise NotImplementedError('decoder module %s is not available on the HIP path' % module)
+        if dropout != 0:
+            raise NotImplementedError('decoder dropout > 0 is not available on the HIP path')
+        if layer > H.MAX_DEC_LAYERS:
+            raise NotImplementedError('at most %d decoder layers' % H.MAX_DEC_LAYERS)
+        self.in_dim, self.layer, self.dim, self.dropout = input_dim, layer, dim, dropout
+        self.enable_cell = True
+        self.layers = LSTMParams(input_dim, dim, False, num_layers=layer)
+        self.char_trans = nn.Linear(dim, vocab_size)
+        self.hidden_state = None
+
+
+class Attention(nn.Module):
+    """Attention parameters: proj_q, proj_k, att_layer (reference src/asr.py:273-364)."""
+
+    def __init__(self, v_dim, q_dim, mode, dim, num_head, temperature, v_proj, loc_kernel_size, loc_kernel_num):
+        super().__init__()
+        self.v_dim, self.dim, self.mode, self.num_head, self.v_proj = v_dim, dim, mode.lower(), num_head, v_proj
+        if self.mode != 'loc' or num_head != 1 or v_proj:
+            raise NotImplementedError("HIP path implements mode='loc', num_head=1, v_proj=False")
+        self.proj_q = nn.Linear(q_dim, dim * num_head)
+        self.proj_k = nn.Linear(v_dim, dim * num_head)
+        self.att_layer = LocationAwareAttention(loc_kernel_size, loc_kernel_num, dim, num_head, temperature)
+
+
+class ASR(nn.Module):
+    ''' ASR model, including Encoder/Decoder(s) — HIP implementation '''
+
+    def __init__(self, input_size, vocab_size, batch_size, ctc_weight, encoder, attention=None, decoder=None, emb_drop=0.0,
+                 init_adadelta=True, prec='bf16', seed=0):
+        super().__init__()
+        assert 0 <= ctc_weight <= 1
+        if emb_drop != 0.0:
+            raise NotImplementedError('emb_drop > 0 is not available on the HIP path')
+        self.vocab_size = vocab_size
+        self.ctc_weight = ctc_weight
+        self.enable_ctc = ctc_weight > 0
+        self.enable_att = ctc_weight != 1
+        self.lm = None
+        self.prec = H.BF16 if str(prec).lower() in ('bf16', '1') else H.F32
+        self.seed = int(seed)
+        self._drop_counter = 0
+
+        self.encoder = Encoder(input_size, batch_size, **encoder)
+        if self.enable_ctc:
+            self.ctc_layer = nn.Sequential(nn.Linear(self.encoder.out_dim, vocab_size), nn.ReLU())
+        if self.enable_att:
+            self.dec_dim = decoder['dim']
+            self.pre_embed = nn.Embedding(vocab_size, self.dec_dim)
+            self.decoder = Decoder(batch_size, self.encoder.out_dim + self.dec_dim, vocab_size, **decoder)
+            self.attention = Attention(self.encoder.out_dim, self.dec_dim * self.decoder.layer, **attention)
+
+        # same end state as the reference's init (src/asr.py:44-50, src/util.py:60-88)
+        init_weights_(self)
+        if self.enable_att:
+            for l in range(self.decoder.layer):
+                init_gate_(getattr(self.decoder.layers, 'bias_ih_l{}'.format(l)))
+
+        self.flat_param = None
+        self.flat_grad = None
+        self._anchor = None
+        self._flatten()
+
+    # ---- flat parameter storage ---------------------------------------------------------------------
+    def _param_groups_for_flat(self):
+        groups, seen = [], set()
+        for m in self.modules():
+            if isinstance(m, RNNLayer):
+                for g in m.flat_groups():
+                    groups.append(g)
+                    seen.update(id(p) for p in g)
+        for p in self.parameters():
+            if id(p) not in seen:
+                groups.append([p])
+        return groups
+
+    def _flatten(self):
+        params = list(self.parameters())
+        if not params:
+            return
+        dev = params[0].device
+        groups = self._param_groups_for_flat()
+        offs, off = {}, 0
+        for g in groups:
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
+            for p in g:
+                offs[id(p)] = off
+                off += p.numel()
+        total = (off + ALIGN - 1) // ALIGN * ALIGN
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p in params:
+            o, n = offs[id(p)], p.numel()
+            flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + n].view(p.shape)
+            p.grad = grad[o:o + n].view(p.shape)
+        self.flat_param, self.flat_grad, self._offsets = flat, grad, offs
+        self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+
+        def view_of(ps, shape, is_grad):
+            o = offs[id(ps[0])]
+            n = sum(p.numel() for p in ps)
+            return (grad if is_grad else flat)[o:o + n].view(shape)
+        for m in self.modules():
+            if hasattr(m, 'bind_flat'):
+                m.bind_flat(view_of)
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        self._flatten()
+        return self
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+
+    # ---- reference surface --------------------------------------------------------------------------
+    def set_state(self, prev_state, prev_attn):
+        self.decoder.hidden_state = prev_state
+        self.attention.att_layer.set_mem(prev_attn)
+
+    def create_msg(self):
+        msg = ['Model spec.| Encoder\'s downsampling rate of time axis is {}.'.format(self.encoder.sample_rate)]
+        if self.encoder.vgg == 1:
+            msg.append('           | VGG Extractor w/ time downsampling rate = 4 in encoder enabled.')
+        if self.encoder.vgg == 5:
+            msg.append('           | VGG Extractor w/ Layer normalization and downsampling rate = 4.')
+        if self.enable_ctc:
+            msg.append('           | CTC training on encoder enabled ( lambda = {}).'.format(self.ctc_weight))
+        if self.enable_att:
+            msg.append('           | {} attention decoder enabled ( lambda = {}).'.format(self.attention.mode, 1 - self.ctc_weight))
+        msg.append('           | HIP path (gfx950), contraction precision = {}.'.format('bf16' if self.prec == H.BF16 else 'fp32'))
+        return msg
+
+    def forward(self, audio_feature, feature_len, decode_step, tf_rate=0.0, teacher=None,
+                emb_decoder=None, get_dec_state=False, get_logit=False):
+        '''Same contract as the reference (src/asr.py:89-177):
+            audio_feature [B,T,D] fp32, feature_len [B], decode_step int, teacher [B,L] token ids or None.
+           Returns ctc_output [B,T',V] (log-probs), encode_len [B], att_output [B,L,V] (logits),
+                   att_seq [B,1,L,T'], dec_state.'''
+        if not audio_feature.is_cuda:
+            raise RuntimeError('ASR (HIP path) needs CUDA tensors; there is no CPU fallback')
+        if emb_decoder is not None:
+            raise NotImplementedError('embedding-regulariser plugin is outside the HIP path')
+        if teacher is not None and tf_rate != 1:
+            raise NotImplementedError('scheduled sampling (tf_rate < 1) is not available on the HIP path')
+        ctx = _RunCtx(self)
+        feature_len = feature_len.to(audio_feature.device)
+        ctc_output, att_output, att_seq, dec_state = None, None, None, None
+        encode_feature, encode_len = self.encoder(audio_feature.float(), feature_len, ctx)
+        if self.enable_ctc:
+            ctc_output = F_hip.CTCHeadFn.apply(ctx.anchor, encode_feature, self.ctc_layer[0], self.prec, get_logit)
+        if self.enable_att:
+            L = int(decode_step)
+            att_output, att_seq, hs = F_hip.AttDecoderFn.apply(ctx.anchor, encode_feature, encode_len, teacher, L, self, self.prec)
+            if get_dec_state:
+                dec_state = hs[:, :, -1, :]
+        return ctc_output, encode_len, att_output, att_seq, dec_state
+
+    def fix_ctc_layer(self):
+        for param in self.ctc_layer.parameters():
+            param.requires_grad = False

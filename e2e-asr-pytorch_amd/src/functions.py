@@ -1,0 +1,302 @@
+"""Autograd bookkeeping around the HIP kernels (libasr_hip.so).
+
+Each torch.autograd.Function below covers one coarse stage of the reference graph and calls the C ABI
+for all arithmetic.  Parameter gradients are accumulated by the kernels directly into the model's flat
+gradient buffer (the views held in `param.grad`); the Functions therefore return gradients only for
+activations.  `anchor` is a dummy requires-grad tensor that keeps autograd calling `backward` even when
+the acoustic features themselves need no gradient.
+"""
+import ctypes
+
+import torch
+
+from src import hipabi as H
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# --------------------------------------------------------------------------------------------------
+# encoder RNN layer: BiLSTM -> [LayerNorm] -> dropout -> time down-sampling -> tanh(Linear)
+# (reference RNNLayer.forward, src/module.py:1040-1081)
+# --------------------------------------------------------------------------------------------------
+class RNNLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, layer, train, seed, prec):
+        x = x.contiguous()
+        B, T, Din = x.shape
+        Hd, ND = layer.dim, layer.nd
+        G = ND * 4 * Hd
+        D = ND * Hd
+        st = H.stream_ptr()
+        gates = _empty((B, T, ND, 4 * Hd), x)
+        H.gemm(x, layer.w_ih_cat, gates, B * T, G, Din, Din, Din, G, 1, 1, bias=layer.b_ih_cat, prec=prec)
+        y = _empty((B, T, D), x)
+        c = _empty((B, T, ND, Hd), x)
+        H.call('asr_lstm_fwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(layer.b_hh_cat), H.ptr(y), H.ptr(c),
+               B, T, Hd, ND, prec, st)
+        yn, stats = y, None
+        if layer.layer_norm:
+            yn = _empty((B, T, D), x)
+            stats = _empty((B * T, 2), x)
+            H.call('asr_layernorm_fwd', H.ptr(y), H.ptr(layer.ln.weight), H.ptr(layer.ln.bias), H.ptr(yn), H.ptr(stats),
+                   B * T, D, 1e-5, 0, st)
+        p = float(layer.dropout) if train else 0.0
+        r, style = layer.sample_rate, (0 if layer.sample_style == 'drop' else 1)
+        if r == 1:
+            T2, Dz = T, D
+        elif style == 0:
+            T2, Dz = (T + r - 1) // r, D
+        else:
+            T2, Dz = T // r, D * r
+        alias = (r == 1 and p == 0.0)
+        if alias:
+            z = yn
+        else:
+            z = _empty((B, T2, Dz), x)
+            H.call('asr_dropout_downsample_fwd', H.ptr(yn), H.ptr(z), B, T, D, T2, r, style, p, seed, st)
+        if layer.proj:
+            out = _empty((B, T2, Dz), x)
+            H.linear_fwd(z.view(B * T2, Dz), layer.pj.weight, layer.pj.bias, out.view(B * T2, Dz), act=H.ACT_TANH, prec=prec)
+        else:
+            out = z
+        ctx.layer, ctx.prec, ctx.meta = layer, prec, (B, T, Din, T2, Dz, p, seed, alias, style)
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(x, gates, c, y, z, out, *( [stats] if stats is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        layer, prec = ctx.layer, ctx.prec
+        B, T, Din, T2, Dz, p, seed, alias, style = ctx.meta
+        saved = ctx.saved_tensors
+        x, gates, c, y, z, out = saved[:6]
+        stats = saved[6] if len(saved) > 6 else None
+        Hd, ND = layer.dim, layer.nd
+        G, D = ND * 4 * Hd, ND * Hd
+        st = H.stream_ptr()
+        dout = dout.contiguous()
+        if layer.proj:
+            dpre = _empty((B * T2, Dz), x)
+            H.call('asr_act_bwd', H.ptr(dout), H.ptr(out), H.ptr(dpre), B * T2 * Dz, H.ACT_TANH, st)
+            dz = _empty((B, T2, Dz), x)
+            H.linear_bwd(z.view(B * T2, Dz), layer.pj.weight, dpre, layer.pj.weight.grad, layer.pj.bias.grad,
+                         dz.view(B * T2, Dz), prec=prec)
+        else:
+            dz = dout
+        if alias:
+            dyn = dz
+        else:
+            dyn = _empty((B, T, D), x)
+            H.call('asr_dropout_downsample_bwd', H.ptr(dz), H.ptr(dyn), B, T, D, T2, layer.sample_rate, style, p, seed, st)
+        if layer.layer_norm:
+            dy = _empty((B, T, D), x)
+            H.call('asr_layernorm_bwd', H.ptr(dyn), H.ptr(y), H.ptr(layer.ln.weight), H.ptr(layer.ln.bias), H.ptr(stats),
+                   H.ptr(dy), H.ptr(layer.ln.weight.grad), H.ptr(layer.ln.bias.grad), B * T, D, 0, st)
+        else:
+            dy = dyn
+        nbytes = H.lib().asr_lstm_bwd_workspace_bytes(B, Hd, ND)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        H.call('asr_lstm_bwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(dy), H.ptr(c), B, T, Hd, ND, prec,
+               H.ptr(ws), nbytes, st)
+        # gates now holds the gradient wrt the gate pre-activations
+        g2 = gates.view(B * T, G)
+        x2 = x.view(B * T, Din)
+        splits = H.wgrad_splits(B * T)
+        H.gemm(g2, x2, layer.g_w_ih_cat, G, Din, B * T, G, Din, Din, 0, 0, accum=1, splits=splits, prec=prec)
+        H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_ih_cat), st)
+        H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_hh_cat), st)
+        y2 = y.view(B * T, D)
+        for d in range(ND):
+            H.gemm(g2[:, d * 4 * Hd:], y2[:, d * Hd:], layer.g_w_hh_cat[d], 4 * Hd, Hd, B * T, G, D, Hd, 0, 0,
+                   accum=1, splits=splits, seqT=T, bshift=(-1 if d == 0 else 1), prec=prec)
+        dx = None
+        if ctx.need_dx:
+            dx = _empty((B, T, Din), x)
+            H.gemm(g2, layer.w_ih_cat, dx, B * T, Din, G, G, Din, Din, 1, 0, prec=prec)
+        return None, dx, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# CTC head: log_softmax(ReLU(Linear(enc)))   (src/asr.py:29-32,116-120)
+# --------------------------------------------------------------------------------------------------
+class CTCHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, enc, lin, prec, get_logit):
+        enc = enc.contiguous()
+        B, T, E = enc.shape
+        V = lin.weight.shape[0]
+        act = _empty((B, T, V), enc)
+        H.linear_fwd(enc.view(B * T, E), lin.weight, lin.bias, act.view(B * T, V), act=H.ACT_RELU, prec=prec)
+        ctx.lin, ctx.prec, ctx.get_logit = lin, prec, get_logit
+        if get_logit:
+            ctx.save_for_backward(enc, act)
+            return act
+        logp = _empty((B, T, V), enc)
+        H.call('asr_log_softmax', H.ptr(act), H.ptr(logp), B * T, V, H.stream_ptr())
+        ctx.save_for_backward(enc, act, logp)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        lin, prec = ctx.lin, ctx.prec
+        g = g.contiguous()
+        if ctx.get_logit:
+            enc, act = ctx.saved_tensors
+            B, T, E = enc.shape
+            V = act.shape[-1]
+            dpre = _empty((B * T, V), enc)
+            H.call('asr_act_bwd', H.ptr(g), H.ptr(act), H.ptr(dpre), B * T * V, H.ACT_RELU, H.stream_ptr())
+        else:
+            enc, act, logp = ctx.saved_tensors
+            B, T, E = enc.shape
+            V = act.shape[-1]
+            dpre = _empty((B * T, V), enc)
+            H.call('asr_logsoftmax_relu_bwd', H.ptr(g), H.ptr(logp), H.ptr(act), H.ptr(dpre), B * T, V, H.stream_ptr())
+        denc = _empty((B, T, E), enc)
+        H.linear_bwd(enc.view(B * T, E), lin.weight, dpre, lin.weight.grad, lin.bias.grad, denc.view(B * T, E), prec=prec)
+        return None, denc, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# CTC loss (torch.nn.CTCLoss(blank=0, zero_infinity=False), bin/train_asr.py:135,237)
+# --------------------------------------------------------------------------------------------------
+class CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp_btv, targets, input_len, target_len):
+        logp = logp_btv.contiguous()
+        B, T, V = logp.shape
+        targets = targets.contiguous()
+        L = targets.shape[1]
+        dev = logp.device
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        grad = _empty((B, T, V), logp)
+        nbytes = H.lib().asr_ctc_loss_workspace_bytes(B, T, L)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # locals keep the converted tensors alive until the kernel has been enqueued on this stream
+        targets = targets.to(dev, torch.int64)
+        il = input_len.to(dev, torch.int64).contiguous()
+        tl = target_len.to(dev, torch.int64).contiguous()
+        H.call('asr_ctc_loss', H.ptr(logp), H.ptr(targets), H.ptr(il), H.ptr(tl), H.ptr(nll), H.ptr(loss), H.ptr(grad),
+               B, T, V, L, 1.0, H.ptr(ws), nbytes, H.stream_ptr())
+        ctx.save_for_backward(grad)
+        ctx.nll = nll
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return grad * gout, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# sequence loss on decoder logits (CrossEntropyLoss(ignore_index=0) / LabelSmoothingLoss)
+# --------------------------------------------------------------------------------------------------
+class SeqLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits_rv, target_r, mode, classes, smoothing):
+        logits = logits_rv.contiguous()
+        R, V = logits.shape
+        tgt = target_r.to(logits_rv.device, torch.int64).contiguous()
+        dev = logits.device
+        dl = _empty((R, V), logits)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        acc = torch.empty(2, dtype=torch.float32, device=dev)
+        H.call('asr_xent', H.ptr(logits), H.ptr(tgt), R, H.ptr(dl), H.ptr(loss), H.ptr(acc), 1, R, V, mode, classes,
+               smoothing, 1.0, H.stream_ptr())
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dl,) = ctx.saved_tensors
+        return dl * gout, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# attention decoder loop (src/asr.py:123-175)
+# --------------------------------------------------------------------------------------------------
+def _dec_dims(model, B, Tp, L):
+    att, dec = model.attention, model.decoder
+    d = H.DecDims()
+    d.B, d.Tp, d.E = B, Tp, model.encoder.out_dim
+    d.A, d.Q = att.dim, dec.dim * dec.layer
+    d.Dd, d.NL, d.V = dec.dim, dec.layer, model.vocab_size
+    d.Kn, d.Ks = att.att_layer.kernel_num, att.att_layer.kernel_size
+    d.L = L
+    d.temperature = float(att.att_layer.temperature)
+    return d
+
+
+def _dec_tensors(model, grads):
+    att, dec, al = model.attention, model.decoder, model.attention.att_layer
+    g = (lambda p: p.grad) if grads else (lambda p: p)
+    nl = dec.layer
+    return {
+        'Wq': g(att.proj_q.weight), 'bq': g(att.proj_q.bias), 'Wk': g(att.proj_k.weight), 'bk': g(att.proj_k.bias),
+        'Wconv': g(al.loc_conv.weight), 'Wproj': g(al.loc_proj.weight), 'wg': g(al.gen_energy.weight), 'bg': g(al.gen_energy.bias),
+        'emb': g(model.pre_embed.weight),
+        'Wih': [g(getattr(dec.layers, 'weight_ih_l%d' % l)) for l in range(nl)],
+        'Whh': [g(getattr(dec.layers, 'weight_hh_l%d' % l)) for l in range(nl)],
+        'bih': [g(getattr(dec.layers, 'bias_ih_l%d' % l)) for l in range(nl)],
+        'bhh': [g(getattr(dec.layers, 'bias_hh_l%d' % l)) for l in range(nl)],
+        'Wc': g(dec.char_trans.weight), 'bc': g(dec.char_trans.bias),
+    }
+
+
+def _dec_state(d, dev):
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    return {
+        'key': f(d.B, d.Tp, d.A), 'att': f(d.B, d.L, d.Tp), 'q': f(d.B, d.L, d.A), 'xin': f(d.B, d.L, d.Dd + d.E),
+        'gates': f(d.B, d.L, d.NL, 4 * d.Dd), 'cs': f(d.B, d.L, d.NL, d.Dd), 'hs': f(d.B, d.L, d.NL, d.Dd),
+        'logits': f(d.B, d.L, d.V), 'energy': f(d.B, d.Tp),
+        'tokens': torch.empty((d.B, d.L), dtype=torch.int64, device=dev),
+    }
+
+
+def att_decoder_forward(model, enc, enc_len, L, teacher, prec):
+    """Runs the decode loop; returns (dims, state dict)."""
+    B, Tp, _ = enc.shape
+    d = _dec_dims(model, B, Tp, L)
+    st = _dec_state(d, enc.device)
+    w = H.dec_weights_struct(_dec_tensors(model, False), d.NL)
+    s = H.dec_state_struct(st)
+    t_ptr, t_ld = (None, 0)
+    if teacher is not None:
+        teacher = teacher.contiguous()
+        assert teacher.shape[1] >= L - 1
+        t_ptr, t_ld = H.ptr(teacher), teacher.shape[1]
+    H.call('asr_att_decoder_fwd', ctypes.byref(d), ctypes.byref(w), H.ptr(enc), H.ptr(enc_len), t_ptr, t_ld,
+           ctypes.byref(s), prec, H.stream_ptr())
+    return d, st
+
+
+class AttDecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, enc, enc_len, teacher, L, model, prec):
+        enc = enc.contiguous()
+        enc_len = enc_len.to(enc.device, torch.int64).contiguous()
+        d, st = att_decoder_forward(model, enc, enc_len, L, teacher, prec)
+        ctx.model, ctx.prec, ctx.d, ctx.st = model, prec, d, st
+        ctx.save_for_backward(enc, enc_len)
+        att_seq = st['att'].view(d.B, 1, d.L, d.Tp)
+        ctx.mark_non_differentiable(att_seq)
+        return st['logits'], att_seq, st['hs']
+
+    @staticmethod
+    def backward(ctx, dlogits, _datt, _dhs):
+        model, prec, d, st = ctx.model, ctx.prec, ctx.d, ctx.st
+        enc, enc_len = ctx.saved_tensors
+        dlogits = dlogits.contiguous()
+        denc = torch.zeros_like(enc)
+        w = H.dec_weights_struct(_dec_tensors(model, False), d.NL)
+        g = H.dec_weights_struct(_dec_tensors(model, True), d.NL)
+        s = H.dec_state_struct(st)
+        nbytes = H.lib().asr_att_decoder_bwd_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+        H.call('asr_att_decoder_bwd', ctypes.byref(d), ctypes.byref(w), ctypes.byref(g), H.ptr(enc), H.ptr(enc_len),
+               ctypes.byref(s), H.ptr(dlogits), H.ptr(denc), H.ptr(ws), nbytes, prec, H.stream_ptr())
+        ctx.st = None
+        return None, denc, None, None, None, None, None

@@ -13,17 +13,58 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libasr_hip.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+MAX_DEC_LAYERS = 4
 
-_vp, _i, _l, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
+_vp, _i, _l, _f, _u64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
+
+
+class DecDims(ctypes.Structure):
+    _fields_ = [(n, _i) for n in ('B', 'Tp', 'E', 'A', 'Q', 'Dd', 'NL', 'V', 'Kn', 'Ks', 'L')] + [('temperature', _f)]
+
+
+_DEC_W_FIELDS = ['Wq', 'bq', 'Wk', 'bk', 'Wconv', 'Wproj', 'wg', 'bg', 'emb']
+
+
+class DecWeights(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in _DEC_W_FIELDS] + \
+               [(n, _vp * MAX_DEC_LAYERS) for n in ('Wih', 'Whh', 'bih', 'bhh')] + [('Wc', _vp), ('bc', _vp)]
+
+
+class DecState(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ('key', 'att', 'q', 'xin', 'gates', 'cs', 'hs', 'logits', 'energy', 'tokens')]
+
+
+_P = ctypes.POINTER
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
     'asr_gemm': [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _l, _l, _l, _i, _i, _i, _vp],
+    'asr_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'asr_lstm_bwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
+    'asr_dropout_downsample_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u64, _vp],
+    'asr_dropout_downsample_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u64, _vp],
+    'asr_dropout_mask': [_vp, _l, _f, _u64, _vp],
+    'asr_act_bwd': [_vp, _vp, _vp, _l, _i, _vp],
+    'asr_colsum': [_vp, _l, _i, _i, _vp, _vp],
+    'asr_log_softmax': [_vp, _vp, _l, _i, _vp],
+    'asr_logsoftmax_relu_bwd': [_vp, _vp, _vp, _vp, _l, _i, _vp],
+    'asr_layernorm_fwd': [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp],
+    'asr_layernorm_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp],
+    'asr_ctc_loss': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp],
+    'asr_xent': [_vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
+    'asr_att_decoder_fwd': [_P(DecDims), _P(DecWeights), _vp, _vp, _vp, _i, _P(DecState), _i, _vp],
+    'asr_att_decoder_bwd': [_P(DecDims), _P(DecWeights), _P(DecWeights), _vp, _vp, _P(DecState), _vp, _vp, _vp, _sz, _i, _vp],
+    'asr_sumsq': [_vp, _l, _vp, _vp],
+    'asr_scale': [_vp, _l, _f, _vp],
+    'asr_adadelta_step': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp],
 }
 _RESTYPES = {
-    'asr_last_error': ctypes.c_char_p,
-    'asr_device_arch': ctypes.c_char_p,
-    'asr_version': ctypes.c_int,
+    'asr_last_error': (ctypes.c_char_p, []),
+    'asr_device_arch': (ctypes.c_char_p, []),
+    'asr_version': (ctypes.c_int, []),
+    'asr_lstm_bwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'asr_ctc_loss_workspace_bytes': (_sz, [_i, _i, _i]),
+    'asr_att_decoder_bwd_workspace_bytes': (_sz, [_P(DecDims)]),
 }
 
 
@@ -41,9 +82,9 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
-    for name, rt in _RESTYPES.items():
+    for name, (rt, at) in _RESTYPES.items():
         fn = getattr(lib, name)
-        fn.argtypes = []
+        fn.argtypes = at
         fn.restype = rt
     return lib
 
@@ -91,3 +132,45 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, bias=None, act=ACT_NON
     """Raw contraction on (views of) fp32 CUDA tensors; see include/asr_hip.h::asr_gemm."""
     call('asr_gemm', ptr(_f32c(A)), ptr(_f32c(B)), ptr(_f32c(C)), ptr(bias), M, N, K, lda, ldb, ldc,
          a_kc, b_kc, act, accum, splits, batch, sA, sB, sC, seqT, bshift, prec, stream_ptr())
+
+
+def wgrad_splits(rows):
+    """Number of reduction slices for a weight-gradient contraction over `rows` = B*T rows."""
+    return max(1, min(32, rows // 1024))
+
+
+def linear_fwd(x2d, W, b, out2d, act=ACT_NONE, prec=BF16):
+    """out = act(x W^T + b): x (M,K) contiguous rows, W (N,K)."""
+    M, K = x2d.shape
+    N = W.shape[0]
+    gemm(x2d, W, out2d, M, N, K, x2d.stride(0), W.stride(0), out2d.stride(0), 1, 1, bias=b, act=act, prec=prec)
+
+
+def linear_bwd(x2d, W, dy2d, dW, db, dx2d=None, prec=BF16, accum_dx=0):
+    """dW += dy^T x ; db += colsum(dy) ; dx (=|+=) dy W."""
+    M, K = x2d.shape
+    N = W.shape[0]
+    gemm(dy2d, x2d, dW, N, K, M, dy2d.stride(0), x2d.stride(0), dW.stride(0), 0, 0, accum=1, splits=wgrad_splits(M), prec=prec)
+    if db is not None:
+        call('asr_colsum', ptr(dy2d), dy2d.stride(0), M, N, ptr(db), stream_ptr())
+    if dx2d is not None:
+        gemm(dy2d, W, dx2d, M, K, N, dy2d.stride(0), W.stride(0), dx2d.stride(0), 1, 0, accum=accum_dx, prec=prec)
+
+
+def dec_weights_struct(tensors, nl):
+    """tensors: dict with keys of _DEC_W_FIELDS + Wc, bc + lists Wih/Whh/bih/bhh."""
+    w = DecWeights()
+    for n in _DEC_W_FIELDS + ['Wc', 'bc']:
+        setattr(w, n, tensors[n].data_ptr())
+    for n in ('Wih', 'Whh', 'bih', 'bhh'):
+        arr = getattr(w, n)
+        for l in range(nl):
+            arr[l] = tensors[n][l].data_ptr()
+    return w
+
+
+def dec_state_struct(tensors):
+    s = DecState()
+    for n, _ in DecState._fields_:
+        setattr(s, n, tensors[n].data_ptr())
+    return s

@@ -62,6 +62,145 @@ int asr_gemm(const float* A, const float* B, float* C, const float* bias,
              int batch, long sA, long sB, long sC, int seqT, int bshift,
              int prec, asr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Encoder BiLSTM time recurrence (the sequential half of nn.LSTM(bidirectional, batch_first),
+ * src/module.py:1023,1049; zero initial state; padded frames are processed like the reference does).
+ *   gates (B,T,ND,4H): in  = x W_ih^T + b_ih + b_hh for every frame (asr_gemm, gate order i,f,g,o)
+ *                      out = activated gates (saved for backward)
+ *   whh   (ND,4H,H)  : weight_hh_l0 [, weight_hh_l0_reverse]
+ *   bias2 (ND,4H)    : optional second bias (bias_hh) added here when `gates` only carries bias_ih
+ *   y     (B,T,ND*H) : h of both directions (forward half first);  c (B,T,ND,H): cell states
+ * Backward consumes dy (gradient wrt y) and overwrites `gates` with the gradient wrt the gate
+ * pre-activations, from which the caller forms dW_ih, dW_hh (shifted rows), db and dx with asr_gemm.
+ * workspace: asr_lstm_bwd_workspace_bytes(B,H,ND), 16B aligned.
+ */
+int asr_lstm_fwd(float* gates, const float* whh, const float* bias2, float* y, float* c,
+                 int B, int T, int H, int ND, int prec, asr_stream_t stream);
+size_t asr_lstm_bwd_workspace_bytes(int B, int H, int ND);
+int asr_lstm_bwd(float* gates, const float* whh, const float* dy, const float* c,
+                 int B, int T, int H, int ND, int prec,
+                 void* workspace, size_t workspace_bytes, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dropout + time down-sampling between the LSTM and `pj` (src/module.py:1059-1076).
+ *   style 0 'drop'  : z[b,t2,:]      = drop(y)[b, t2*rate, :]          z is (B,T2,D)
+ *   style 1 'concat': z[b,t2,i*D+:]  = drop(y)[b, t2*rate+i, :]        z is (B,T2,D*rate)
+ * keep(element) = Philox4x32-10(seed, flat index in y) >= p*2^32, kept values scaled by 1/(1-p);
+ * asr_dropout_mask exports the same {0,1} mask (tests feed it to the oracle).  p = 0: no dropout.
+ * Backward writes the full dy (B,T,D), zeros where nothing flowed.
+ */
+int asr_dropout_downsample_fwd(const float* y, float* z, int B, int T, int D, int T2, int rate, int style,
+                               float p, uint64_t seed, asr_stream_t stream);
+int asr_dropout_downsample_bwd(const float* dz, float* dy, int B, int T, int D, int T2, int rate, int style,
+                               float p, uint64_t seed, asr_stream_t stream);
+int asr_dropout_mask(float* mask, long n, float p, uint64_t seed, asr_stream_t stream);
+
+/* dpre = dout * act'(out) for act in {TANH, RELU} (autograd of torch.tanh / nn.ReLU on the path). */
+int asr_act_bwd(const float* dout, const float* out, float* dpre, long n, int act, asr_stream_t stream);
+/* out[j] += sum_i A[i*lda + j]  (bias gradients). */
+int asr_colsum(const float* A, long lda, int M, int N, float* out, asr_stream_t stream);
+/* row-wise log_softmax (src/asr.py:120) and the backward of log_softmax(ReLU(.)) of the CTC head
+ * (src/asr.py:29-32,120): dpre = (act > 0) ? dlogp - exp(logp) * rowsum(dlogp) : 0. */
+int asr_log_softmax(const float* x, float* out, long rows, int V, asr_stream_t stream);
+int asr_logsoftmax_relu_bwd(const float* dlogp, const float* logp, const float* act, float* dpre,
+                            long rows, int V, asr_stream_t stream);
+/* LayerNorm over the last axis (+ optional fused ReLU): nn.LayerNorm in RNNLayer.ln (src/module.py:1031,1057)
+ * and CNNLayerNorm (src/module.py:546-550).  stats (rows,2) = mean, rstd.  dw/db are accumulated. */
+int asr_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* stats,
+                      long rows, int n, float eps, int relu, asr_stream_t stream);
+int asr_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* stats,
+                      float* dx, float* dw, float* db, long rows, int n, int relu, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CTC loss, torch.nn.CTCLoss(blank=0, zero_infinity=False) with reduction 'mean' as called at
+ * bin/train_asr.py:135,237 (inputs are batch-major here: logp (B,T,V)).
+ *   nll (B) per-utterance negative log-likelihood; *loss = mean_b nll_b / max(target_len_b,1)
+ *   grad (B,T,V) = gscale * d loss / d logits in the folded form torch returns for log-softmax inputs
+ *   (exp(logp) - posterior), exactly 0 for t >= input_len; +inf / NaN for infeasible alignments.
+ * workspace: asr_ctc_loss_workspace_bytes(B,T,L) (alpha lattice).
+ */
+size_t asr_ctc_loss_workspace_bytes(int B, int T, int L);
+int asr_ctc_loss(const float* logp, const int64_t* targets, const int64_t* input_len, const int64_t* target_len,
+                 float* nll, float* loss, float* grad, int B, int T, int V, int L, float gscale,
+                 void* workspace, size_t workspace_bytes, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sequence loss of the attention decoder + gradient (bin/train_asr.py:131-134,245; src/util.py:11-25).
+ *   mode 0: CrossEntropyLoss(ignore_index=0);  mode 1: LabelSmoothingLoss(classes, smoothing)
+ *   logits (B,L,V); targets (B,target_ld) int64; dlogits = gscale * d loss / d logits; accum2: 2 floats scratch.
+ */
+int asr_xent(const float* logits, const int64_t* targets, long target_ld, float* dlogits, float* loss,
+             float* accum2, int B, int L, int V, int mode, int classes, float smoothing, float gscale,
+             asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention decoder loop (src/asr.py:123-175; Attention.forward :333-364; LocationAwareAttention
+ * src/module.py:1152-1173; Decoder.forward src/asr.py:259-266; pre_embed :35,128-133), num_head = 1,
+ * v_proj = False, teacher forcing (tf_rate = 1) when `teacher` is given, greedy argmax otherwise.
+ */
+#define ASR_MAX_DEC_LAYERS 4
+typedef struct {
+    int B, Tp, E;       /* batch, encoder frames T', encoder feature dim */
+    int A, Q;           /* attention dim, query dim = Dd*NL */
+    int Dd, NL, V;      /* decoder LSTM dim, layers, vocabulary */
+    int Kn, Ks;         /* loc_kernel_num, loc_kernel_size (taps = 2*Ks+1) */
+    int L;              /* decode steps */
+    float temperature;
+} asr_dec_dims_t;
+
+typedef struct {        /* reference state_dict tensors */
+    const float *Wq, *bq;            /* attention.proj_q  (A,Q),(A) */
+    const float *Wk, *bk;            /* attention.proj_k  (A,E),(A) */
+    const float *Wconv;              /* attention.att_layer.loc_conv.weight (Kn,1,2Ks+1) */
+    const float *Wproj;              /* attention.att_layer.loc_proj.weight (A,Kn) */
+    const float *wg, *bg;            /* attention.att_layer.gen_energy (1,A),(1) */
+    const float *emb;                /* pre_embed.weight (V,Dd) */
+    const float *Wih[ASR_MAX_DEC_LAYERS], *Whh[ASR_MAX_DEC_LAYERS];   /* decoder.layers.weight_{ih,hh}_l* */
+    const float *bih[ASR_MAX_DEC_LAYERS], *bhh[ASR_MAX_DEC_LAYERS];
+    const float *Wc, *bc;            /* decoder.char_trans (V,Dd),(V) */
+} asr_dec_weights_t;
+
+typedef struct {        /* gradient accumulators, same shapes (+=) */
+    float *Wq, *bq, *Wk, *bk, *Wconv, *Wproj, *wg, *bg, *emb;
+    float *Wih[ASR_MAX_DEC_LAYERS], *Whh[ASR_MAX_DEC_LAYERS], *bih[ASR_MAX_DEC_LAYERS], *bhh[ASR_MAX_DEC_LAYERS];
+    float *Wc, *bc;
+} asr_dec_grads_t;
+
+typedef struct {        /* forward outputs / saved activations, caller-allocated */
+    float* key;         /* (B,Tp,A)   tanh(proj_k(enc)) */
+    float* att;         /* (B,L,Tp)   attention weights per step (= att_seq of the reference, num_head 1) */
+    float* q;           /* (B,L,A)    tanh(proj_q(.)) */
+    float* xin;         /* (B,L,Dd+E) decoder input [embedding | context] */
+    float* gates;       /* (B,L,NL,4Dd) activated gates; overwritten with pre-activation gradients by backward */
+    float* cs;          /* (B,L,NL,Dd) */
+    float* hs;          /* (B,L,NL,Dd) */
+    float* logits;      /* (B,L,V)    att_output */
+    float* energy;      /* (B,Tp)     scratch */
+    int64_t* tokens;    /* (B,L)      input token of each step (<sos>=0 first) */
+} asr_dec_state_t;
+
+int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights,
+                        const float* enc, const int64_t* enc_len, const int64_t* teacher, int teacher_ld,
+                        const asr_dec_state_t* state, int prec, asr_stream_t stream);
+size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims);
+/* dlogits (B,L,V) in; denc (B,Tp,E) accumulated (+=); parameter gradients accumulated into `grads`.
+ * workspace must be 256B aligned. */
+int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights, const asr_dec_grads_t* grads,
+                        const float* enc, const int64_t* enc_len, const asr_dec_state_t* state,
+                        const float* dlogits, float* denc,
+                        void* workspace, size_t workspace_bytes, int prec, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat-buffer step: global-norm clip + NaN guard (src/solver.py:96-103) fused with torch.optim.Adadelta
+ * (src/optim.py:29,53-54).  normsq: device pointer to the sum of squares of `grad` (asr_sumsq);
+ * grad_mul is applied to the stored gradient first (1/world_size when the buffer holds an all-reduced sum).
+ */
+int asr_sumsq(const float* x, long n, double* out, asr_stream_t stream);
+int asr_scale(float* x, long n, float k, asr_stream_t stream);
+int asr_adadelta_step(float* param, const float* grad, float* square_avg, float* acc_delta, long n,
+                      float lr, float rho, float eps, float weight_decay, float clip,
+                      const double* normsq, float grad_mul, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

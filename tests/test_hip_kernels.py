@@ -1,0 +1,199 @@
+"""Kernel-level parity through the C ABI (ctypes) against the CPU oracle / plain fp32 torch on the CPU.
+fp32 contraction mode is held to accumulation-order noise; bf16 mode to the tolerances of SURVEY §8d."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda(*ts):
+    return [t.cuda() for t in ts]
+
+
+@pytest.mark.parametrize('prec', [0, 1])
+@pytest.mark.parametrize('B,T,H,ND', [(3, 11, 16, 2), (5, 7, 20, 1), (18, 9, 32, 2), (16, 33, 320, 2)])
+def test_lstm_recurrence_fwd_bwd(B, T, H, ND, prec):
+    from src import hipabi as Hh
+    g = torch.Generator().manual_seed(B * 100 + T + H)
+    Din = 12
+    x = torch.randn(B, T, Din, generator=g)
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    P = {}
+    for sfx in ([''] + (['_reverse'] if ND == 2 else [])):
+        P['weight_ih_l0' + sfx] = torch.randn(4 * H, Din, generator=g) / Din ** 0.5
+        P['weight_hh_l0' + sfx] = torch.randn(4 * H, H, generator=g) / H ** 0.5
+        P['bias_ih_l0' + sfx] = torch.randn(4 * H, generator=g) * 0.1
+        P['bias_hh_l0' + sfx] = torch.randn(4 * H, generator=g) * 0.1
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    y_ref = O.bilstm(xr, Pr, '', ND == 2)
+    dy = torch.randn(B, T, ND * H, generator=g)
+    (y_ref * dy).sum().backward()
+
+    sfxs = [''] + (['_reverse'] if ND == 2 else [])
+    wih = torch.cat([P['weight_ih_l0' + s] for s in sfxs]).cuda()
+    whh = torch.stack([P['weight_hh_l0' + s] for s in sfxs]).cuda().contiguous()
+    bih = torch.cat([P['bias_ih_l0' + s] for s in sfxs]).cuda()
+    bhh = torch.cat([P['bias_hh_l0' + s] for s in sfxs]).cuda()
+    xd = x.cuda()
+    G = ND * 4 * H
+    gates = torch.empty(B, T, ND, 4 * H, device='cuda')
+    Hh.gemm(xd, wih, gates, B * T, G, Din, Din, Din, G, 1, 1, bias=bih, prec=prec)
+    y = torch.empty(B, T, ND * H, device='cuda')
+    c = torch.empty(B, T, ND, H, device='cuda')
+    st = Hh.stream_ptr()
+    Hh.call('asr_lstm_fwd', Hh.ptr(gates), Hh.ptr(whh), Hh.ptr(bhh), Hh.ptr(y), Hh.ptr(c), B, T, H, ND, prec, st)
+    tol = 2e-5 if prec == 0 else 3e-2
+    assert (y.cpu() - y_ref.detach()).abs().max().item() < tol
+    nbytes = Hh.lib().asr_lstm_bwd_workspace_bytes(B, H, ND)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    dyd = dy.cuda()
+    Hh.call('asr_lstm_bwd', Hh.ptr(gates), Hh.ptr(whh), Hh.ptr(dyd), Hh.ptr(c), B, T, H, ND, prec, Hh.ptr(ws), nbytes, st)
+    # dx and dW from the pre-activation gradients
+    dx = torch.empty(B, T, Din, device='cuda')
+    g2 = gates.view(B * T, G)
+    Hh.gemm(g2, wih, dx, B * T, Din, G, G, Din, Din, 1, 0, prec=prec)
+    dwih = torch.zeros(G, Din, device='cuda')
+    Hh.gemm(g2, xd.view(B * T, Din), dwih, G, Din, B * T, G, Din, Din, 0, 0, accum=1, prec=prec)
+    dwhh = torch.zeros(ND, 4 * H, H, device='cuda')
+    y2 = y.view(B * T, ND * H)
+    for d in range(ND):
+        Hh.gemm(g2[:, d * 4 * H:], y2[:, d * H:], dwhh[d], 4 * H, H, B * T, G, ND * H, H, 0, 0, accum=1, seqT=T,
+                bshift=(-1 if d == 0 else 1), prec=prec)
+    db = torch.zeros(G, device='cuda')
+    Hh.call('asr_colsum', Hh.ptr(g2), G, B * T, G, Hh.ptr(db), st)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a.cpu().double() - b.double()).norm() / (b.double().norm() + 1e-12))
+    rtol = 1e-4 if prec == 0 else 4e-2
+    assert rel(dx, xr.grad) < rtol
+    assert rel(dwih, torch.cat([Pr['weight_ih_l0' + s].grad for s in sfxs])) < rtol
+    assert rel(dwhh, torch.stack([Pr['weight_hh_l0' + s].grad for s in sfxs])) < rtol
+    assert rel(db, torch.cat([Pr['bias_ih_l0' + s].grad for s in sfxs])) < rtol
+
+
+def test_ctc_loss_fixture_and_torch(golden_dir):
+    from src import hipabi as Hh
+    z = np.load(os.path.join(golden_dir, 'g4_ctc.npz'))
+    logits, txt, in_len = torch.from_numpy(z['logits']), torch.from_numpy(z['txt']), torch.from_numpy(z['in_len'])
+    B, T, V = logits.shape
+    L = txt.shape[1]
+    lp = torch.log_softmax(logits, -1)
+    tl = (txt != 0).sum(-1)
+
+    def run(lp_, txt_, il_, tl_):
+        B_, T_, V_ = lp_.shape
+        L_ = txt_.shape[1]
+        nll = torch.empty(B_, device='cuda')
+        loss = torch.empty((), device='cuda')
+        grad = torch.empty(B_, T_, V_, device='cuda')
+        nb = Hh.lib().asr_ctc_loss_workspace_bytes(B_, T_, L_)
+        ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+        lpd, txd, ild, tld = lp_.contiguous().cuda(), txt_.cuda(), il_.cuda(), tl_.cuda()   # keep alive until the sync
+        Hh.call('asr_ctc_loss', Hh.ptr(lpd), Hh.ptr(txd), Hh.ptr(ild), Hh.ptr(tld), Hh.ptr(nll),
+                Hh.ptr(loss), Hh.ptr(grad), B_, T_, V_, L_, 1.0, Hh.ptr(ws), nb, Hh.stream_ptr())
+        torch.cuda.synchronize()
+        return nll.cpu(), float(loss), grad.cpu()
+    nll, loss, grad = run(lp, txt, in_len, tl)
+    np.testing.assert_allclose(nll.numpy(), z['nll'], rtol=1e-5, atol=1e-5)
+    assert abs(loss - float(z['loss'])) < 1e-5
+    np.testing.assert_allclose(grad.numpy(), z['grad'], atol=2e-6)
+    # infeasible alignment: inf loss, NaN gradient rows (reference behaviour, zero_infinity=False)
+    nll2, loss2, grad2 = run(lp[:1, :4], torch.tensor([[2, 2, 1]]), torch.tensor([3]), torch.tensor([3]))
+    assert np.isinf(loss2) and torch.isnan(grad2[:, :3]).any() and (grad2[:, 3:] == 0).all()
+    # larger random case against torch on the CPU (ragged, repeated labels, S > 256 states)
+    g = torch.Generator().manual_seed(3)
+    B, T, V, L = 5, 300, 31, 140
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=g), -1)
+    tl = torch.tensor([140, 1, 77, 130, 20])
+    txt = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        txt[b, :tl[b]] = torch.randint(1, V, (int(tl[b]),), generator=g)
+    txt[2, 5:9] = 7
+    il = torch.tensor([300, 10, 200, 299, 41])
+    lpr = lp.clone().requires_grad_(True)
+    ref = F.ctc_loss(lpr.transpose(0, 1), txt, il, tl, blank=0, reduction='mean', zero_infinity=False)
+    ref.backward()
+    nll, loss, grad = run(lp, txt, il, tl)
+    assert abs(loss - float(ref)) < 1e-4 * abs(float(ref))
+    assert (grad - lpr.grad).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_sequence_losses(mode):
+    from src.util import CrossEntropyLoss, LabelSmoothingLoss
+    g = torch.Generator().manual_seed(1)
+    R, V = 77, 31
+    logits = torch.randn(R, V, generator=g) * 2
+    tgt = torch.randint(0, V, (R,), generator=g)
+    tgt[::5] = 0
+    lr = logits.clone().requires_grad_(True)
+    if mode == 0:
+        ref = F.cross_entropy(lr, tgt, ignore_index=0)
+        crit = CrossEntropyLoss(ignore_index=0)
+    else:
+        ref = O.label_smoothing_loss(lr, tgt, 31, 0.1)
+        crit = LabelSmoothingLoss(31, 0.1)
+    (ref * 0.7).backward()
+    ld = logits.cuda().requires_grad_(True)
+    loss = crit(ld, tgt.cuda())
+    (loss * 0.7).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    assert (ld.grad.cpu() - lr.grad).abs().max().item() < 1e-6
+
+
+def test_clip_and_adadelta_step():
+    from src import hipabi as Hh
+    g = torch.Generator().manual_seed(2)
+    n = 100003
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adadelta([pr], lr=1.0, eps=1e-8)
+    pd, sq, ad = p0.cuda(), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    nsq = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for step in range(3):
+        pr.grad = gr.clone() * (step + 1)
+        gn = torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        gd = (gr * (step + 1)).cuda()
+        Hh.call('asr_sumsq', Hh.ptr(gd), n, Hh.ptr(nsq), Hh.stream_ptr())
+        Hh.call('asr_adadelta_step', Hh.ptr(pd), Hh.ptr(gd), Hh.ptr(sq), Hh.ptr(ad), n, 1.0, 0.9, 1e-8, 0.0, 5.0, Hh.ptr(nsq), 1.0,
+                Hh.stream_ptr())
+        assert abs(float(nsq.sqrt()) - float(gn)) < 1e-3 * float(gn)
+    assert (pd.cpu() - pr.data).abs().max().item() < 1e-5
+    # NaN gradient norm: the update is skipped (src/solver.py:99-103)
+    before = pd.clone()
+    nsq.fill_(float('nan'))
+    Hh.call('asr_adadelta_step', Hh.ptr(pd), Hh.ptr(gd), Hh.ptr(sq), Hh.ptr(ad), n, 1.0, 0.9, 1e-8, 0.0, 5.0, Hh.ptr(nsq), 1.0,
+            Hh.stream_ptr())
+    assert torch.equal(before, pd)
+
+
+def test_dropout_downsample_roundtrip():
+    from src import hipabi as Hh
+    B, T, D, r = 3, 11, 8, 2
+    y = torch.randn(B, T, D).cuda()
+    st = Hh.stream_ptr()
+    for style, T2, Dz in ((0, 6, D), (1, 5, D * 2)):
+        z = torch.full((B, T2, Dz), float('nan'), device='cuda')
+        Hh.call('asr_dropout_downsample_fwd', Hh.ptr(y), Hh.ptr(z), B, T, D, T2, r, style, 0.3, 99, st)
+        m = torch.empty(B * T * D, device='cuda')
+        Hh.call('asr_dropout_mask', Hh.ptr(m), m.numel(), 0.3, 99, st)
+        yd = (y * m.view(B, T, D) / 0.7)
+        ref = yd[:, ::r] if style == 0 else yd[:, :T2 * r].reshape(B, T2, Dz)
+        assert torch.allclose(z, ref, atol=1e-6)
+        dz = torch.randn(B, T2, Dz).cuda()
+        dy = torch.full((B, T, D), float('nan'), device='cuda')
+        Hh.call('asr_dropout_downsample_bwd', Hh.ptr(dz), Hh.ptr(dy), B, T, D, T2, r, style, 0.3, 99, st)
+        yr = y.clone().requires_grad_(True)
+        ydr = yr * m.view(B, T, D) / 0.7
+        refz = ydr[:, ::r] if style == 0 else ydr[:, :T2 * r].reshape(B, T2, Dz)
+        (refz * dz).sum().backward()
+        assert torch.allclose(dy, yr.grad, atol=1e-6)

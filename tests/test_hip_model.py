@@ -1,0 +1,189 @@
+"""End-to-end parity of the HIP model (e2e-asr-pytorch_amd/src/asr.ASR + HIP loss modules) against the
+golden fixtures produced by the genuine reference, and against the CPU oracle on the same seeded inputs.
+
+Tolerances: fp32 contraction mode — losses rel 1e-5 (+1e-6), logits/log-probs abs 1e-4,
+gradients rel-L2 1e-4 (+ abs floor); bf16 contraction mode — losses rel 2e-2, outputs abs 5e-2,
+per-parameter gradient cosine >= 0.99 (checked on parameters with non-negligible gradient norm).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + '.npz'), allow_pickle=False)
+    return yaml.safe_load(str(z['meta'])), z
+
+
+def build(meta, prec):
+    from src.asr import ASR
+    cfg = O.ModelCfg(meta['model'], meta['D'], meta['V'])
+    sd = O.seeded_state_dict(O.param_shapes(cfg), meta['wseed'])
+    model = ASR(meta['D'], meta['V'], 4, prec=prec, **meta['model'])
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    model = model.cuda()
+    return cfg, sd, model
+
+
+def hip_step(model, feat, feat_len, txt, label_smoothing):
+    from src.util import CTCLoss, CrossEntropyLoss, LabelSmoothingLoss
+    feat, feat_len, txt = feat.cuda(), feat_len.cuda(), txt.cuda()
+    txt_len = (txt != 0).sum(-1)
+    L = int(txt_len.max())
+    model.zero_grad()
+    ctc_out, enc_len, att_out, att_seq, _ = model(feat, feat_len, L, tf_rate=1.0, teacher=txt)
+    res = {'enc_len': enc_len, 'ctc_output': ctc_out, 'att_output': att_out, 'att_seq': att_seq}
+    total = 0
+    if ctc_out is not None:
+        res['ctc_loss'] = CTCLoss(blank=0, zero_infinity=False)(ctc_out.transpose(0, 1), txt, enc_len, txt_len)
+        total = total + res['ctc_loss'] * model.ctc_weight
+    if att_out is not None:
+        b, t, _ = att_out.shape
+        crit = LabelSmoothingLoss(31, 0.1) if label_smoothing else CrossEntropyLoss(ignore_index=0)
+        res['att_loss'] = crit(att_out.view(b * t, -1), txt[:, :L].reshape(-1))
+        total = total + res['att_loss'] * (1 - model.ctc_weight)
+    res['total_loss'] = total
+    total.backward()
+    torch.cuda.synchronize()
+    return res
+
+
+def compare(model, res, ref_out, ref_grads, prec, report):
+    f32 = (prec == 'fp32')
+    out_tol = 1e-4 if f32 else 5e-2
+    for key in ('ctc_output', 'att_output', 'att_seq'):
+        if key in ref_out and ref_out[key] is not None:
+            got = res[key].detach().float().cpu().numpy()
+            err = float(np.abs(got - ref_out[key]).max())
+            report.append((key, err, out_tol, err <= out_tol))
+    for key in ('ctc_loss', 'att_loss', 'total_loss'):
+        if key in ref_out and ref_out[key] is not None:
+            r = float(ref_out[key])
+            err = abs(float(res[key].detach()) - r)
+            tol = (1e-5 if f32 else 2e-2) * max(1.0, abs(r)) + 1e-6
+            report.append((key, err, tol, err <= tol))
+    gmax = max(float(np.linalg.norm(g)) for g in ref_grads.values())
+    for k, p in model.named_parameters():
+        g = p.grad.detach().cpu().numpy().astype(np.float64)
+        r = ref_grads[k].astype(np.float64)
+        rn = np.linalg.norm(r)
+        if f32:
+            err = np.linalg.norm(g - r)
+            tol = 1e-4 * rn + 1e-6 * max(gmax, 1.0)
+            report.append(('grad.' + k, err, tol, err <= tol))
+        elif rn > 1e-3 * gmax:
+            cos = float((g * r).sum() / (np.linalg.norm(g) * rn + 1e-30))
+            report.append(('gradcos.' + k, 1 - cos, 0.01, cos >= 0.99))
+
+
+def finish(report):
+    bad = [r for r in report if not r[3]]
+    msg = '\n'.join('%-60s err %.3e tol %.3e %s' % (n, e, t, 'ok' if ok else 'FAIL') for n, e, t, ok in report)
+    assert not bad, '\n' + msg
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('name', ['g1_small_c2', 'g3_small_debug', 'g3_small_ln_concat'])
+def test_small_models_vs_reference_fixtures(golden_dir, name, prec):
+    meta, z = load(golden_dir, name)
+    cfg, sd, model = build(meta, prec)
+    model.eval()
+    res = hip_step(model, torch.from_numpy(z['feat']), torch.from_numpy(z['feat_len']), torch.from_numpy(z['txt']),
+                   meta['label_smoothing'])
+    assert np.array_equal(res['enc_len'].cpu().numpy(), z['enc_len'])
+    ref_out = {k: (z[k] if k in z.files else None) for k in ('ctc_output', 'att_output', 'att_seq', 'ctc_loss', 'att_loss', 'total_loss')}
+    ref_grads = {k: z['grad.' + k] for k in sd}
+    report = []
+    compare(model, res, ref_out, ref_grads, prec, report)
+    finish(report)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_training_mode_dropout_vs_oracle(golden_dir, prec):
+    """Dropout on: the HIP Philox mask is exported (asr_dropout_mask) and fed to the CPU oracle."""
+    from src import hipabi as H
+    meta, z = load(golden_dir, 'g1_small_c2_dropout')
+    cfg, sd, model = build(meta, prec)
+    model.train()
+    model.seed, model._drop_counter = 5, 0
+    feat, flen, txt = torch.from_numpy(z['feat']), torch.from_numpy(z['feat_len']), torch.from_numpy(z['txt'])
+    res = hip_step(model, feat, flen, txt, False)
+    masks = []
+    B, T = feat.shape[:2]
+    for l in range(2):
+        seed = (5 * 1000003 + l + 1) & 0xFFFFFFFFFFFF
+        Tl = T  # both layers see T frames (layer 1 down-samples after its LSTM)
+        m = torch.empty(B * Tl * 32, device='cuda')
+        H.call('asr_dropout_mask', H.ptr(m), m.numel(), cfg.enc_dropout[l], seed, H.stream_ptr())
+        masks.append(m.view(B, Tl, 32).cpu())
+        assert 0.6 < float(m.mean()) < 0.9
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.asr_losses(feat, flen, txt, P, cfg, label_smoothing=False, drop_masks=masks)
+    ref['total_loss'].backward()
+    ref_out = {k: (ref[k].detach().numpy() if torch.is_tensor(ref.get(k)) else None)
+               for k in ('ctc_output', 'att_output', 'att_seq', 'ctc_loss', 'att_loss', 'total_loss')}
+    ref_grads = {k: P[k].grad.numpy() for k in sd}
+    report = []
+    compare(model, res, ref_out, ref_grads, prec, report)
+    finish(report)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_full_size_librispeech_config(golden_dir, prec):
+    """config/librispeech_asr.yaml (12.08 M parameters), B=4, T=203, L=11 — fixture summaries."""
+    import importlib.util
+    meta, z = load(golden_dir, 'g2_full_c2')
+    spec = importlib.util.spec_from_file_location('batchgen', os.path.join(golden_dir, 'batchgen.py'))
+    bg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bg)
+    feat, lens, txt = bg.make_batch(int(z['feat_seed']), 4, 203, 160, 11, 31)
+    cfg, sd, model = build(meta, prec)
+    model.eval()
+    res = hip_step(model, torch.from_numpy(feat), torch.from_numpy(lens), torch.from_numpy(txt), False)
+    f32 = prec == 'fp32'
+    report = []
+    for key in ('ctc_loss', 'att_loss', 'total_loss'):
+        r = float(z[key])
+        err = abs(float(res[key].detach()) - r)
+        tol = (2e-5 if f32 else 2e-2) * max(1.0, abs(r))
+        report.append((key, err, tol, err <= tol))
+    out_tol = 2e-4 if f32 else 5e-2
+    for key, sl in (('ctc_output', np.s_[:, :4]), ('att_output', np.s_[:, :4]), ('att_seq', np.s_[:, :, :4])):
+        err = float(np.abs(res[key].detach().cpu().numpy()[sl] - z[key + '_head']).max())
+        report.append((key, err, out_tol, err <= out_tol))
+    gmax = max(float(z['gradnorm.' + k]) for k in sd)
+    for k, p in model.named_parameters():
+        r = float(z['gradnorm.' + k])
+        n = float(p.grad.norm())
+        tol = (5e-4 if f32 else 5e-2) * r + 1e-5 * gmax
+        report.append(('gradnorm.' + k, abs(n - r), tol, abs(n - r) <= tol))
+        if f32:
+            err = float(np.abs(p.grad.reshape(-1)[:8].cpu().numpy() - z['gradhead.' + k]).max())
+            tol = 2e-4 * r + 1e-6 * gmax
+            report.append(('gradhead.' + k, err, tol, err <= tol))
+    finish(report)
+
+
+def test_greedy_decoding_matches_reference(golden_dir):
+    meta, z = load(golden_dir, 'g1_small_c2')
+    cfg, sd, model = build(meta, 'fp32')
+    model.eval()
+    L = int((z['txt'] != 0).sum(-1).max())
+    with torch.no_grad():
+        _, _, att_out, _, _ = model(torch.from_numpy(z['feat']).cuda(), torch.from_numpy(z['feat_len']).cuda(), int(L * 1.2))
+    assert np.array_equal(att_out.argmax(-1).cpu().numpy(), z['greedy_argmax'])
+
+
+def test_hip_path_refuses_cpu_tensors(golden_dir):
+    meta, z = load(golden_dir, 'g1_small_c2')
+    cfg, sd, model = build(meta, 'fp32')
+    with pytest.raises(RuntimeError):
+        model(torch.from_numpy(z['feat']), torch.from_numpy(z['feat_len']), 3)

@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Throughput of the joint CTC-attention training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one synthetic LibriSpeech-shaped batch per GPU, inputs already
+resident in HBM: forward (4 x BiLSTM-320 encoder, CTC head, location-aware attention decoder) + CTC and
+cross-entropy losses + backward + [RCCL all-reduce of the flat gradient] + global-norm clip + Adadelta.
+Workload = BASELINE.json configs[1]: config/librispeech_asr.yaml, B=16 x T=1200 frames of 160-dim
+fbank+delta per GPU, L=180 tokens, bf16 MFMA contractions with fp32 accumulate, dropout on.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'e2e-asr-pytorch_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='utterances per GPU')
+    ap.add_argument('--frames', type=int, default=1200)
+    ap.add_argument('--tokens', type=int, default=180)
+    ap.add_argument('--prec', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--config', default=os.path.join(PKG, 'config', 'librispeech_asr.yaml'))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    return ap.parse_args()
+
+
+class KernelTimer(object):
+    """HIP-event timing of selected C-ABI calls on the stream they are launched on (torch's current stream)."""
+
+    def __init__(self, names):
+        self.names, self.records, self.enabled = set(names), [], False
+
+    def wrap(self, H):
+        orig = H.call
+        timer = self
+
+        def call(name, *args):
+            if timer.enabled and name in timer.names:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(name, *args)
+                e1.record()
+                timer.records.append((name, args, e0, e1))
+            else:
+                orig(name, *args)
+        H.call = call
+
+    def summary(self):
+        out = {}
+        for name, args, e0, e1 in self.records:
+            out.setdefault(name, []).append((args, e0.elapsed_time(e1)))
+        return out
+
+
+def cpu_baseline(cfg_model, D, V, seconds):
+    """The CPU restatement (oracle, torch fused LSTM on the host cores) on a bounded sample of the same
+    workload: B=4 x T=600 frames, L=90 tokens, fwd+bwd, repeated for ~`seconds`."""
+    from oracle import asr_oracle as O
+    from src.synthetic import librispeech_shaped_batch
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))     # the GPU box grants a 16-CPU share per GPU; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    cfg = O.ModelCfg(cfg_model, D, V)
+    P = {k: v.requires_grad_(True) for k, v in O.seeded_state_dict(O.param_shapes(cfg), 1).items()}
+    B, T, L = 4, 600, 90
+    feat, lens, txt = librispeech_shaped_batch(B, T, D, L, V, seed=7)
+    n, t0 = 0, time.time()
+    log('cpu baseline: %d threads' % cores)
+    while True:
+        res = O.asr_losses(feat, lens, txt, P, cfg, lstm_impl=O.bilstm_aten)
+        res['total_loss'].backward()
+        for p in P.values():
+            p.grad = None
+        n += 1
+        log('cpu baseline pass %d at %.1f s' % (n, time.time() - t0))
+        if time.time() - t0 > seconds and n >= 2:
+            break
+    dt = time.time() - t0
+    return {'value': B * T * n / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle (plain PyTorch CPU restatement, fp32, fused ATen LSTM) fwd+bwd on B=%d x T=%d x L=%d, %d passes in %.1f s'
+                      % (B, T, L, n, dt)}
+
+
+def log(msg):
+    print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    from src import dist as D_
+    rank, world, local = D_.init_from_env('nccl' if args.gpus > 1 else None)
+    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    from src import hipabi as H
+    from src.asr import ASR
+    from src.optim import Optimizer
+    from src.step import train_step
+    from src.synthetic import librispeech_shaped_batch
+    from src.util import CTCLoss, CrossEntropyLoss, LabelSmoothingLoss
+
+    config = yaml.safe_load(open(args.config))
+    Dfeat = config['data']['audio']['feat_dim'] * (config['data']['audio']['delta_order'] + 1)
+    V = 31
+    torch.manual_seed(0)
+    model = ASR(Dfeat, V, args.batch, prec=args.prec, seed=1234 + rank, **config['model']).cuda().train()
+    dp = None
+    if world > 1:
+        dp = model.attach_data_parallel()
+        dp.broadcast_params(0)
+    hp = config['hparas']
+    optimizer = Optimizer(model.parameters(), hp['optimizer'], hp['lr'], hp['eps'], hp.get('lr_scheduler'),
+                          hp.get('tf_start', 1), hp.get('tf_end', 1), hp.get('tf_step', 1))
+    ctc_crit = CTCLoss(blank=0, zero_infinity=False)
+    att_crit = LabelSmoothingLoss(31, 0.1) if hp.get('label_smoothing', False) else CrossEntropyLoss(ignore_index=0)
+    B, T, L = args.batch, args.frames, args.tokens
+    feat, feat_len, txt = librispeech_shaped_batch(B, T, Dfeat, L, V, seed=1234 + rank, device='cuda')
+    txt_len = (txt != 0).sum(-1)
+
+    timer = KernelTimer(['asr_lstm_fwd', 'asr_lstm_bwd', 'asr_att_decoder_fwd', 'asr_att_decoder_bwd'])
+    timer.wrap(H)
+
+    def step():
+        return train_step(model, optimizer, ctc_crit, att_crit, feat, feat_len, txt, L, tf_rate=1.0, dp=dp, clip=5.0,
+                          txt_len=txt_len)
+
+    log('model built (%d params), warm-up...' % sum(p.numel() for p in model.parameters()))
+    for i in range(args.warmup):
+        out = step()
+        torch.cuda.synchronize()
+        log('warm-up step %d done, loss %.4f' % (i, float(out['total_loss'])))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax)
+    loss = float(out['total_loss'])
+    log('timed %d steps in %.3f s' % (args.steps, dt))
+    frames = B * T * world * args.steps
+    valid = int(feat_len.sum()) * world * args.steps
+    if rank != 0:
+        return
+
+    # ---- roofline of the dominant kernel: the encoder LSTM recurrence step ------------------------
+    summ = timer.summary()
+    enc = config['model']['encoder']
+    Hd, ND = enc['dim'][0], 2 if enc['bidirection'] else 1
+    tot = {k: sum(ms for _, ms in v) for k, v in summ.items()}
+    launches_f = sum(a[6] for a, _ in summ.get('asr_lstm_fwd', []))      # T of every call = launches
+    launches_b = sum(a[5] for a, _ in summ.get('asr_lstm_bwd', []))
+    dominant = max(tot, key=tot.get) if tot else None
+    roof = None
+    if launches_f:
+        # algorithmic bytes of ONE launch of lstm_fwd_step (both directions, all B rows), fp32 storage:
+        #   W_hh (ND*4H*H) read + per row: gate pre-activations read and activated gates written (2*ND*4H),
+        #   h_{t-1}, c_{t-1} read and h_t, c_t written (4*ND*H)
+        bytes_f = 4.0 * (ND * 4 * Hd * Hd + B * (2 * ND * 4 * Hd + 4 * ND * Hd))
+        avg_f = tot['asr_lstm_fwd'] * 1e-3 / launches_f
+        roof = {'kernel': 'lstm_fwd_step', 'bound': 'hbm', 'achieved': bytes_f / avg_f / 1e9, 'peak': 8000.0,
+                'unit': 'GB/s', 'frac': bytes_f / avg_f / 1e9 / 8000.0, 'traffic': None,
+                'avg_launch_us': avg_f * 1e6, 'launches_per_step': launches_f / args.steps,
+                'algorithmic_bytes_per_launch': bytes_f}
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        log('cpu baseline (oracle) for ~%.0f s...' % args.cpu_seconds)
+        cpu = cpu_baseline(config['model'], Dfeat, V, args.cpu_seconds)
+    line = {
+        'metric': 'audio frames/sec (fwd+bwd) LibriSpeech-100 joint CTC-att',
+        'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.prec, 'data': 'synthetic',
+        'config': {'workload': 'config/librispeech_asr.yaml (vgg 0, 4xBiLSTM-320, joint CTC-att 0.5), B=%d x T=%d x D=%d per GPU, L=%d, '
+                               'fwd+losses+bwd+grad-allreduce+clip+Adadelta, dropout on' % (B, T, Dfeat, L),
+                   'global_batch': B * world, 'frames_per_utt': T, 'parallelism': 'dp%d' % world},
+        'valid_frames_per_s': valid / dt, 'loss': loss,
+        'stage_ms_per_step': {k: v / args.steps for k, v in tot.items()},
+        'roofline': roof, 'cpu_baseline': cpu,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

@@ -113,28 +113,41 @@ __device__ __forceinline__ bf16x8 load8_bf16(const float* p, int k, int kend, bo
 }
 
 // acc += A(16 x K) * B(K x 16) where lane (l&15) addresses row `arow` of A and column-row `brow` of B,
-// both K-contiguous in memory; k-steps kbeg, kbeg+kstride, ...
-template <bool BF16>
+// both K-contiguous in memory; k-steps ks_beg, ks_beg+ks_stride, ...  The loads of U k-steps are issued
+// together before the MFMAs so that one memory round trip covers U steps (these kernels are latency-bound).
+template <bool BF16, int U = 8>
 __device__ __forceinline__ f32x4 dot_rows(const float* arow, bool aok, const float* brow, bool bok, int K,
                                           int ks_beg, int ks_stride, bool vec, f32x4 acc) {
     const int q = (threadIdx.x & 63) >> 4;
     if (BF16) {
         const int nks = (K + 31) >> 5;
-        for (int ks = ks_beg; ks < nks; ks += ks_stride) {
-            const int k = ks * 32 + 8 * q;
-            bf16x8 a = load8_bf16(arow, k, K, aok, vec);
-            bf16x8 b = load8_bf16(brow, k, K, bok, vec);
-            acc = mma16(a, b, acc);
+        for (int ks0 = ks_beg; ks0 < nks; ks0 += U * ks_stride) {
+            bf16x8 a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ks = ks0 + u * ks_stride;
+                const int k = ks * 32 + 8 * q;
+                const bool in = ks < nks;
+                a[u] = load8_bf16(arow, k, K, aok && in, vec);
+                b[u] = load8_bf16(brow, k, K, bok && in, vec);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = mma16(a[u], b[u], acc);
         }
     } else {
         const int nks = (K + 3) >> 2;
-        for (int ks = ks_beg; ks < nks; ks += ks_stride) {
-            const int k = ks * 4 + q;
-            float a = (aok && k < K) ? arow[k] : 0.f;
-            float b = (bok && k < K) ? brow[k] : 0.f;
-            acc = mma16(a, b, acc);
+        constexpr int UF = 4 * U;
+        for (int ks0 = ks_beg; ks0 < nks; ks0 += UF * ks_stride) {
+            float a[UF], b[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int k = (ks0 + u * ks_stride) * 4 + q;
+                a[u] = (aok && k < K) ? arow[k] : 0.f;
+                b[u] = (bok && k < K) ? brow[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) acc = mma16(a[u], b[u], acc);
         }
     }
     return acc;
 }
-

@@ -16,6 +16,9 @@ namespace {
 
 constexpr int TT = 64;  // encoder frames per workgroup in the energy kernels
 
+// tanh via one v_exp: 1 - 2/(1+e^{2x}); absolute error ~1e-7 (the energy kernels evaluate ~6 M of these per step)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+
 struct DecP {
     asr_dec_dims_t d;
     asr_dec_weights_t w;
@@ -94,12 +97,19 @@ __device__ __forceinline__ void conv_tile(const DecP& p, int b, int t, int tau0,
     }
     for (int i = threadIdx.x; i < d.Kn * taps; i += blockDim.x) s_wc[i] = p.w.Wconv[i];
     __syncthreads();
-    for (int o = threadIdx.x; o < d.Kn * TT; o += blockDim.x) {
-        const int i = o % TT, k = o / TT;
+    // each thread produces 4 consecutive frames of one kernel with a sliding register window
+    for (int o = threadIdx.x; o < d.Kn * (TT / 4); o += blockDim.x) {
+        const int i0 = (o % (TT / 4)) * 4, k = o / (TT / 4);
         const float* wk = s_wc + k * taps;
-        float acc = 0.f;
-        for (int j = 0; j < taps; ++j) acc += wk[j] * s_pa[i + j];
-        s_conv[o] = acc;
+        float w0 = s_pa[i0], w1 = s_pa[i0 + 1], w2 = s_pa[i0 + 2];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int j = 0; j < taps; ++j) {
+            const float w3 = s_pa[i0 + j + 3 < win ? i0 + j + 3 : win - 1];
+            const float c = wk[j];
+            a0 += c * w0; a1 += c * w1; a2 += c * w2; a3 += c * w3;
+            w0 = w1; w1 = w2; w2 = w3;
+        }
+        s_conv[k * TT + i0] = a0; s_conv[k * TT + i0 + 1] = a1; s_conv[k * TT + i0 + 2] = a2; s_conv[k * TT + i0 + 3] = a3;
     }
     __syncthreads();
 }
@@ -123,22 +133,26 @@ __global__ __launch_bounds__(256) void att_energy_kernel(DecP p, int t) {
     float e[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) e[i] = 0.f;
+    const int tmax = max(min(len, d.Tp) - 1, 0);
     for (int a = lane; a < d.A; a += 64) {
         float wp[KNMAX];
 #pragma unroll
         for (int k = 0; k < KNMAX; ++k) wp[k] = (k < d.Kn) ? p.w.Wproj[(long)a * d.Kn + k] : 0.f;
         const float qa = qrow[a], wga = p.w.wg[a];
+        float kv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // all 16 key loads of this column in flight together
+            const int tau = min(tau0 + wave * 16 + i, tmax);
+            kv[i] = p.s.key[((long)b * d.Tp + tau) * d.A + a];
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ti = wave * 16 + i;
-            const int tau = tau0 + ti;
-            if (tau < len) {
-                float lp = 0.f;
+            float lp = 0.f;
 #pragma unroll
-                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
-                const float u = tanhf(p.s.key[((long)b * d.Tp + tau) * d.A + a] + qa + tanhf(lp));
-                e[i] += wga * u;
-            }
+            for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
+            const float u = tanh_fast(kv[i] + qa + tanh_fast(lp));
+            e[i] += (tau0 + ti < len) ? wga * u : 0.f;
         }
     }
 #pragma unroll
@@ -192,17 +206,54 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(DecP p, int t) {
         if (blockIdx.x == 0) p.s.att[((long)b * d.L + t) * d.Tp + i] = a;
     }
     __syncthreads();
-    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int ecol = e0 + col;
-    float acc = 0.f;
-    if (ecol < d.E) {
-        const float* ep = p.enc + (long)b * d.Tp * d.E + ecol;
-        for (int tau = grp; tau < len; tau += 4) acc += s_att[tau] * ep[(long)tau * d.E];
+    float* xrow = p.s.xin + ((long)b * d.L + t) * (d.Dd + d.E) + d.Dd;
+    if ((d.E & 3) == 0) {
+        // 16 lanes x float4 cover the block's 64 columns; 16 frame groups, 4 independent loads in flight each
+        const int c4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+        const int ecol = e0 + 4 * c4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ecol < d.E) {
+            const float* ep = p.enc + (long)b * d.Tp * d.E + ecol;
+            int tau = grp;
+            for (; tau + 48 < len; tau += 64) {
+                const float4 v0 = *reinterpret_cast<const float4*>(ep + (long)tau * d.E);
+                const float4 v1 = *reinterpret_cast<const float4*>(ep + (long)(tau + 16) * d.E);
+                const float4 v2 = *reinterpret_cast<const float4*>(ep + (long)(tau + 32) * d.E);
+                const float4 v3 = *reinterpret_cast<const float4*>(ep + (long)(tau + 48) * d.E);
+                const float a0 = s_att[tau], a1 = s_att[tau + 16], a2 = s_att[tau + 32], a3 = s_att[tau + 48];
+                acc.x += a0 * v0.x + a1 * v1.x + a2 * v2.x + a3 * v3.x;
+                acc.y += a0 * v0.y + a1 * v1.y + a2 * v2.y + a3 * v3.y;
+                acc.z += a0 * v0.z + a1 * v1.z + a2 * v2.z + a3 * v3.z;
+                acc.w += a0 * v0.w + a1 * v1.w + a2 * v2.w + a3 * v3.w;
+            }
+            for (; tau < len; tau += 16) {
+                const float4 v0 = *reinterpret_cast<const float4*>(ep + (long)tau * d.E);
+                const float a0 = s_att[tau];
+                acc.x += a0 * v0.x; acc.y += a0 * v0.y; acc.z += a0 * v0.z; acc.w += a0 * v0.w;
+            }
+        }
+        __shared__ float4 red4[16][16];
+        red4[grp][c4] = acc;
+        __syncthreads();
+        if (threadIdx.x < 16 && e0 + 4 * threadIdx.x < d.E) {
+            float4 r = red4[0][threadIdx.x];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) { const float4 v = red4[g][threadIdx.x]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+            float* o = xrow + e0 + 4 * threadIdx.x;
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+        }
+    } else {
+        const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+        const int ecol = e0 + col;
+        float acc = 0.f;
+        if (ecol < d.E) {
+            const float* ep = p.enc + (long)b * d.Tp * d.E + ecol;
+            for (int tau = grp; tau < len; tau += 4) acc += s_att[tau] * ep[(long)tau * d.E];
+        }
+        red[grp][col] = acc;
+        __syncthreads();
+        if (grp == 0 && ecol < d.E) xrow[ecol] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
     }
-    red[grp][col] = acc;
-    __syncthreads();
-    if (grp == 0 && ecol < d.E)
-        p.s.xin[((long)b * d.L + t) * (d.Dd + d.E) + d.Dd + ecol] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,19 +424,29 @@ __global__ __launch_bounds__(256) void att_bwd_dattn_kernel(DecB p, int t, int l
     const float* dctx = p.dxin + ((long)b * d.L + t) * (d.Dd + d.E) + d.Dd;
     for (int i = threadIdx.x; i < d.E; i += 256) smem_f[i] = dctx[i];
     __syncthreads();
-    for (int i = 0; i < 16; ++i) {
-        const int tau = tau0 + wave * 16 + i;
-        if (tau >= d.Tp) break;
-        float acc = 0.f;
-        if (tau < len) {
-            const float* er = p.f.enc + ((long)b * d.Tp + tau) * d.E;
-            for (int e = lane; e < d.E; e += 64) acc += smem_f[e] * er[e];
+    const int tmax = max(len - 1, 0);
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+        const int tb = tau0 + wave * 16 + i0;
+        if (tb >= d.Tp) break;
+        const float* r0 = p.f.enc + ((long)b * d.Tp + min(tb, tmax)) * d.E;
+        const float* r1 = p.f.enc + ((long)b * d.Tp + min(tb + 1, tmax)) * d.E;
+        const float* r2 = p.f.enc + ((long)b * d.Tp + min(tb + 2, tmax)) * d.E;
+        const float* r3 = p.f.enc + ((long)b * d.Tp + min(tb + 3, tmax)) * d.E;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+        for (int e = lane; e < d.E; e += 64) {
+            const float c = smem_f[e];
+            a0 += c * r0[e]; a1 += c * r1[e]; a2 += c * r2[e]; a3 += c * r3[e];
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float v = (tau < len) ? acc : 0.f;
-            if (!last && tau < len) v += p.datt_next[(long)b * d.Tp + tau];
-            p.dattn[(long)b * d.Tp + tau] = v;
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+        if (lane < 4) {
+            const int tau = tb + lane;
+            if (tau < d.Tp) {
+                float v = (lane == 0) ? a0 : (lane == 1) ? a1 : (lane == 2) ? a2 : a3;
+                if (tau >= len) v = 0.f;
+                else if (!last) v += p.datt_next[(long)b * d.Tp + tau];
+                p.dattn[(long)b * d.Tp + tau] = v;
+            }
         }
     }
 }
@@ -424,33 +485,37 @@ __global__ __launch_bounds__(256) void att_bwd_energy_kernel(DecB p, int t) {
 
     const float* qrow = p.f.s.q + ((long)b * d.L + t) * d.A;
     float* dqrow = p.dq + ((long)b * d.L + t) * d.A;
+    const int tmax = max(len - 1, 0);
     for (int a = lane; a < d.A; a += 64) {
         float wp[KNMAX], dwp[KNMAX];
 #pragma unroll
         for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? p.f.w.Wproj[(long)a * d.Kn + k] : 0.f; dwp[k] = 0.f; }
         const float qa = qrow[a], wga = p.f.w.wg[a];
         float dwg = 0.f, dqa = 0.f;
-#pragma unroll 4
+        float kv[16], dk[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {   // key and dkey of this column: 32 loads in flight
+            const long ki = ((long)b * d.Tp + min(tau0 + wave * 16 + i, tmax)) * d.A + a;
+            kv[i] = p.f.s.key[ki];
+            dk[i] = p.dkey[ki];
+        }
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ti = wave * 16 + i;
             const int tau = tau0 + ti;
-            float dl = 0.f;
-            if (tau < len) {
-                float lp = 0.f;
+            float lp = 0.f;
 #pragma unroll
-                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
-                const float loc = tanhf(lp);
-                const long ki = ((long)b * d.Tp + tau) * d.A + a;
-                const float u = tanhf(p.f.s.key[ki] + qa + loc);
-                const float de = s_de[ti];
-                const float du = de * wga * (1.f - u * u);
-                dwg += de * u;
-                dqa += du;
-                p.dkey[ki] += du;
-                dl = du * (1.f - loc * loc);
+            for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
+            const float loc = tanh_fast(lp);
+            const float u = tanh_fast(kv[i] + qa + loc);
+            const float de = s_de[ti];                      // 0 for tau >= len
+            const float du = de * wga * (1.f - u * u);
+            const float dl = du * (1.f - loc * loc);
+            dwg += de * u;
+            dqa += du;
 #pragma unroll
-                for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + ti];
-            }
+            for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + ti];
+            if (tau < len) p.dkey[((long)b * d.Tp + tau) * d.A + a] = dk[i] + du;
             s_dl[ti * AP + a] = dl;
         }
         atomicAdd(&s_part[a], dwg);
@@ -499,17 +564,25 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(DecB p, int t) {
     }
     __syncthreads();
     // conv[k][tau] = sum_j W[k][j] pa[tau + j - Ks]  =>  d pa[tau'] = sum_k sum_j W[k][j] dconv[k][tau' - j + Ks]
-    if (t > 0 && threadIdx.x < TT) {
-        const int i = threadIdx.x, tau = tau0 + i;
-        if (tau < d.Tp) {
-            float acc = 0.f;
-            for (int k = 0; k < d.Kn; ++k) {
+    // 4 thread groups split the kernels k; partial sums meet in LDS
+    __shared__ float s_red[4][TT];
+    {
+        const int i = threadIdx.x & 63, kg = threadIdx.x >> 6;
+        float acc = 0.f;
+        if (t > 0) {
+            for (int k = kg; k < d.Kn; k += 4) {
                 const float* wk = s_wc + k * taps;
-                const float* dc = s_dc + k * win + i + 2 * d.Ks;   // index of tau' + Ks  (window offset Ks)
+                const float* dc = s_dc + k * win + i + 2 * d.Ks;   // window index of tau' + Ks
                 for (int j = 0; j < taps; ++j) acc += wk[j] * dc[-j];
             }
-            p.datt_next[(long)b * d.Tp + tau] = acc;
         }
+        s_red[kg][i] = acc;
+    }
+    __syncthreads();
+    if (t > 0 && threadIdx.x < TT) {
+        const int tau = tau0 + threadIdx.x;
+        if (tau < d.Tp)
+            p.datt_next[(long)b * d.Tp + tau] = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
     }
     // d W_conv[k][j] += sum_{tau in tile} dconv[k][tau] * pa[tau + j - Ks]
     float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot + d.A * (1 + d.Kn) + 1;

@@ -8,6 +8,7 @@
 // Launch-per-step form: both directions advance in one launch; h_{t-1} is read straight from the output
 // tensor y and c_{t-1} from the saved cell states, so there is no hidden state besides the outputs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -144,13 +145,38 @@ __global__ void transpose_whh_kernel(const float* __restrict__ w, float* __restr
 
 }  // namespace
 
+// lstm_persist.hip
+int lstm_fwd_persistent(float* gates, const float* whh, const float* bias2, float* y, float* c,
+                        int B, int T, int H, int ND, int prec, void* ws, size_t ws_bytes, hipStream_t st);
+int lstm_bwd_persistent(float* gates, const float* whh, const float* dy, const float* c,
+                        int B, int T, int H, int ND, int prec, void* ws, size_t ws_bytes, hipStream_t st);
+size_t lstm_persist_workspace_bytes(int B, int H, int ND);
+
+static int g_persist = -1;
+static bool persist_enabled() {
+    if (g_persist < 0) { const char* e = getenv("ASR_LSTM_PERSIST"); g_persist = (e && e[0] == '0') ? 0 : 1; }
+    return g_persist == 1;
+}
+extern "C" int asr_lstm_set_persistent(int on) { int old = persist_enabled() ? 1 : 0; g_persist = on ? 1 : 0; return old; }
+
+extern "C" size_t asr_lstm_workspace_bytes(int B, int H, int ND) {
+    size_t step = ((size_t)ND * H * 4 * H + (size_t)ND * B * H) * sizeof(float);
+    size_t per = lstm_persist_workspace_bytes(B, H, ND);
+    return (step > per ? step : per) + 256;
+}
+
 extern "C" int asr_lstm_fwd(float* gates, const float* whh, const float* bias2, float* y, float* c,
-                            int B, int T, int H, int ND, int prec, asr_stream_t stream) {
+                            int B, int T, int H, int ND, int prec,
+                            void* workspace, size_t workspace_bytes, asr_stream_t stream) {
     ASR_REQUIRE(gates && whh && y && c, ASR_E_ARG, "asr_lstm_fwd: null pointer");
     ASR_REQUIRE(B > 0 && T > 0 && H > 0 && (ND == 1 || ND == 2), ASR_E_ARG, "asr_lstm_fwd: bad dims");
     ASR_REQUIRE(((uintptr_t)whh & 15) == 0 && ((uintptr_t)y & 15) == 0, ASR_E_ARG, "asr_lstm_fwd: unaligned");
     LstmP p{gates, whh, y, c, nullptr, bias2, B, T, H, ND};
     hipStream_t st = (hipStream_t)stream;
+    if (workspace && persist_enabled() && ((uintptr_t)workspace & 255) == 0) {
+        int rc = lstm_fwd_persistent(gates, whh, bias2, y, c, B, T, H, ND, prec, workspace, workspace_bytes, st);
+        if (rc <= 0) return rc;
+    }
     dim3 grid(cdiv(H, 4), ND), block(64);
     for (int s = 0; s < T; ++s) {
         if (prec == ASR_BF16) hipLaunchKernelGGL(lstm_fwd_step<true>, grid, block, 0, st, p, s);
@@ -160,19 +186,20 @@ extern "C" int asr_lstm_fwd(float* gates, const float* whh, const float* bias2, 
     return ASR_OK;
 }
 
-extern "C" size_t asr_lstm_bwd_workspace_bytes(int B, int H, int ND) {
-    return ((size_t)ND * H * 4 * H + (size_t)ND * B * H) * sizeof(float);
-}
 
 extern "C" int asr_lstm_bwd(float* gates, const float* whh, const float* dy, const float* c,
                             int B, int T, int H, int ND, int prec,
                             void* workspace, size_t workspace_bytes, asr_stream_t stream) {
     ASR_REQUIRE(gates && whh && dy && c && workspace, ASR_E_ARG, "asr_lstm_bwd: null pointer");
     ASR_REQUIRE(B > 0 && T > 0 && H > 0 && (ND == 1 || ND == 2), ASR_E_ARG, "asr_lstm_bwd: bad dims");
-    ASR_REQUIRE(workspace_bytes >= asr_lstm_bwd_workspace_bytes(B, H, ND), ASR_E_ARG, "asr_lstm_bwd: workspace too small");
-    ASR_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)gates & 15) == 0, ASR_E_ARG, "asr_lstm_bwd: unaligned");
+    ASR_REQUIRE(workspace_bytes >= asr_lstm_workspace_bytes(B, H, ND), ASR_E_ARG, "asr_lstm_bwd: workspace too small");
+    ASR_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)gates & 15) == 0, ASR_E_ARG, "asr_lstm_bwd: unaligned");
     hipStream_t st = (hipStream_t)stream;
-    float* wt = (float*)workspace;
+    if (persist_enabled()) {
+        int rc = lstm_bwd_persistent(gates, whh, dy, c, B, T, H, ND, prec, workspace, workspace_bytes, st);
+        if (rc <= 0) return rc;
+    }
+    float* wt = (float*)((char*)workspace + 256);   // the first 256 bytes belong to the persistent path's status words
     float* dcf = wt + (size_t)ND * H * 4 * H;
     hipLaunchKernelGGL(transpose_whh_kernel, dim3(256), dim3(256), 0, st, whh, wt, ND, H);
     LstmP p{gates, wt, const_cast<float*>(dy), const_cast<float*>(c), dcf, nullptr, B, T, H, ND};

@@ -145,30 +145,38 @@ class ASR(nn.Module):
 
     # ---- flat parameter storage ---------------------------------------------------------------------
     def _param_groups_for_flat(self):
-        groups, seen = [], set()
-        for m in self.modules():
-            if isinstance(m, RNNLayer):
-                for g in m.flat_groups():
-                    groups.append(g)
-                    seen.update(id(p) for p in g)
-        for p in self.parameters():
-            if id(p) not in seen:
-                groups.append([p])
-        return groups
+        """Layout of the flat buffer: every RNN layer's parameters back to back (one bucket per layer),
+        then the front-end (VGG) parameters, then everything else (heads, embedding, decoder, attention)."""
+        sections, seen = [], set()
+        rnn_layers = [m for m in self.encoder.layers if isinstance(m, RNNLayer)]
+        for m in rnn_layers:
+            g = m.flat_groups()
+            sections.append(('rnn', g))
+            seen.update(id(p) for grp in g for p in grp)
+        front = [m for m in self.encoder.layers if not isinstance(m, RNNLayer)]
+        fg = [[p] for m in front for p in m.parameters()]
+        seen.update(id(p) for grp in fg for p in grp)
+        sections.append(('front', fg))
+        sections.append(('rest', [[p] for p in self.parameters() if id(p) not in seen]))
+        return sections
 
     def _flatten(self):
         params = list(self.parameters())
         if not params:
             return
         dev = params[0].device
-        groups = self._param_groups_for_flat()
-        offs, off = {}, 0
-        for g in groups:
+        sections = self._param_groups_for_flat()
+        offs, off, ranges = {}, 0, []
+        for kind, groups in sections:
+            start = (off + ALIGN - 1) // ALIGN * ALIGN
+            for g in groups:
+                off = (off + ALIGN - 1) // ALIGN * ALIGN
+                for p in g:
+                    offs[id(p)] = off
+                    off += p.numel()
             off = (off + ALIGN - 1) // ALIGN * ALIGN
-            for p in g:
-                offs[id(p)] = off
-                off += p.numel()
-        total = (off + ALIGN - 1) // ALIGN * ALIGN
+            ranges.append((kind, start, off))
+        total = off
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         grad = torch.zeros(total, dtype=torch.float32, device=dev)
         for p in params:
@@ -176,7 +184,8 @@ class ASR(nn.Module):
             flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = flat[o:o + n].view(p.shape)
             p.grad = grad[o:o + n].view(p.shape)
-        self.flat_param, self.flat_grad, self._offsets = flat, grad, offs
+            p._asr_flat = (flat, grad, offs)
+        self.flat_param, self.flat_grad, self._offsets, self._ranges = flat, grad, offs, ranges
         self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
 
         def view_of(ps, shape, is_grad):
@@ -186,6 +195,21 @@ class ASR(nn.Module):
         for m in self.modules():
             if hasattr(m, 'bind_flat'):
                 m.bind_flat(view_of)
+
+    def attach_data_parallel(self, group=None):
+        """Creates the flat-bucket gradient reducer (src/dist.py) with buckets in backward-completion order:
+        heads/decoder/attention first, then the encoder RNN layers top-down, the front-end last."""
+        from src.dist import FlatDataParallel
+        rnn = [(s, e) for k, s, e in self._ranges if k == 'rnn']
+        front = [(s, e) for k, s, e in self._ranges if k == 'front' and e > s]
+        rest = [(s, e) for k, s, e in self._ranges if k == 'rest' and e > s]
+        buckets = rest + rnn[::-1] + front
+        dp = FlatDataParallel(self.flat_param, self.flat_grad, buckets, group)
+        layers = [m for m in self.encoder.layers if isinstance(m, RNNLayer)]
+        for i, m in enumerate(layers[::-1]):
+            m.dp, m.bucket = dp, len(rest) + i
+        self._dp, self._n_rest = dp, len(rest)
+        return dp
 
     def _apply(self, fn, *args, **kwargs):
         super()._apply(fn, *args, **kwargs)

@@ -1,0 +1,77 @@
+"""Data parallelism over whole utterances: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests), weights replicated, ONE flat fp32 gradient buffer.
+
+The reference has no distributed code: this is the build's addition (§8e).  Per step:
+  1. (optional, tiny) all-reduce of the non-pad token counts so that the token-mean cross entropy of the
+     global batch is reproduced exactly: rank r scales its attention loss by n_r * R / sum_r n_r;
+  2. all-reduce(SUM) of the flat gradient, issued per bucket as soon as that part of backward is done
+     (decoder + heads first, then encoder layers top-down) so that the transfers overlap the remaining
+     BPTT; averaging (1/R) is folded into the optimizer kernel (`grad_mul`);
+  3. the clip / NaN-skip decision is taken on the REDUCED gradient, so every rank takes the same one.
+Works on any flat tensors, which is what the world_size-2 gloo tests exercise on the CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialises the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatDataParallel(object):
+    def __init__(self, flat_param, flat_grad, buckets=None, group=None):
+        """buckets: list of (start, end) element ranges of the flat buffers in the order backward finishes them."""
+        self.flat_param, self.flat_grad, self.group = flat_param, flat_grad, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = buckets or [(0, flat_grad.numel())]
+        self._handles = []
+        self._done = set()
+
+    @property
+    def grad_mul(self):
+        return 1.0 / self.world
+
+    def broadcast_params(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.flat_param, src, group=self.group)
+
+    def ce_weight(self, n_tokens_local):
+        """Factor for this rank's token-mean loss so that the average over ranks equals the global token mean."""
+        if self.world == 1:
+            return 1.0
+        n = n_tokens_local.detach().to(self.flat_grad.device, torch.float32).reshape(1).clone()
+        tot = n.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        return (n * self.world / tot).reshape(())
+
+    def bucket_ready(self, idx):
+        """Called when backward has finished writing bucket `idx`: starts its all-reduce asynchronously."""
+        if self.world == 1 or idx in self._done:
+            return
+        a, b = self.buckets[idx]
+        self._done.add(idx)
+        self._handles.append(dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Reduces whatever has not been started yet and waits for everything. The buffer then holds the SUM."""
+        if self.world == 1:
+            return
+        for i in range(len(self.buckets)):
+            self.bucket_ready(i)
+        for h in self._handles:
+            h.wait()
+        self._handles, self._done = [], set()

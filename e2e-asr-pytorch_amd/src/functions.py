@@ -34,8 +34,11 @@ class RNNLayerFn(torch.autograd.Function):
         H.gemm(x, layer.w_ih_cat, gates, B * T, G, Din, Din, Din, G, 1, 1, bias=layer.b_ih_cat, prec=prec)
         y = _empty((B, T, D), x)
         c = _empty((B, T, ND, Hd), x)
+        nbytes = H.lib().asr_lstm_workspace_bytes(B, Hd, ND)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         H.call('asr_lstm_fwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(layer.b_hh_cat), H.ptr(y), H.ptr(c),
-               B, T, Hd, ND, prec, st)
+               B, T, Hd, ND, prec, H.ptr(ws), nbytes, st)
+        layer.last_ws = ws
         yn, stats = y, None
         if layer.layer_norm:
             yn = _empty((B, T, D), x)
@@ -77,6 +80,10 @@ class RNNLayerFn(torch.autograd.Function):
         G, D = ND * 4 * Hd, ND * Hd
         st = H.stream_ptr()
         dout = dout.contiguous()
+        if layer.dp is not None:
+            # every consumer of the encoder output has finished its backward: the heads/decoder bucket(s) can go
+            for i in range(layer.bucket - 0):
+                layer.dp.bucket_ready(i)
         if layer.proj:
             dpre = _empty((B * T2, Dz), x)
             H.call('asr_act_bwd', H.ptr(dout), H.ptr(out), H.ptr(dpre), B * T2 * Dz, H.ACT_TANH, st)
@@ -96,10 +103,11 @@ class RNNLayerFn(torch.autograd.Function):
                    H.ptr(dy), H.ptr(layer.ln.weight.grad), H.ptr(layer.ln.bias.grad), B * T, D, 0, st)
         else:
             dy = dyn
-        nbytes = H.lib().asr_lstm_bwd_workspace_bytes(B, Hd, ND)
+        nbytes = H.lib().asr_lstm_workspace_bytes(B, Hd, ND)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         H.call('asr_lstm_bwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(dy), H.ptr(c), B, T, Hd, ND, prec,
                H.ptr(ws), nbytes, st)
+        layer.last_ws_bwd = ws
         # gates now holds the gradient wrt the gate pre-activations
         g2 = gates.view(B * T, G)
         x2 = x.view(B * T, Din)
@@ -115,6 +123,8 @@ class RNNLayerFn(torch.autograd.Function):
         if ctx.need_dx:
             dx = _empty((B, T, Din), x)
             H.gemm(g2, layer.w_ih_cat, dx, B * T, Din, G, G, Din, Din, 1, 0, prec=prec)
+        if layer.dp is not None:
+            layer.dp.bucket_ready(layer.bucket)
         return None, dx, None, None, None, None
 
 

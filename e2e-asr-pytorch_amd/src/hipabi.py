@@ -39,7 +39,7 @@ _P = ctypes.POINTER
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
     'asr_gemm': [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _i, _i, _l, _l, _l, _i, _i, _i, _vp],
-    'asr_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'asr_lstm_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     'asr_lstm_bwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp],
     'asr_dropout_downsample_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u64, _vp],
     'asr_dropout_downsample_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u64, _vp],
@@ -62,7 +62,8 @@ _RESTYPES = {
     'asr_last_error': (ctypes.c_char_p, []),
     'asr_device_arch': (ctypes.c_char_p, []),
     'asr_version': (ctypes.c_int, []),
-    'asr_lstm_bwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'asr_lstm_workspace_bytes': (_sz, [_i, _i, _i]),
+    'asr_lstm_set_persistent': (ctypes.c_int, [_i]),
     'asr_ctc_loss_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_att_decoder_bwd_workspace_bytes': (_sz, [_P(DecDims)]),
 }

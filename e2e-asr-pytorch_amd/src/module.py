@@ -51,11 +51,17 @@ class RNNLayer(nn.Module):
         # concatenated views into the flat buffers, set by ASR._flatten()
         self.w_ih_cat = self.w_hh_cat = self.b_ih_cat = self.b_hh_cat = None
         self.g_w_ih_cat = self.g_w_hh_cat = self.g_b_ih_cat = self.g_b_hh_cat = None
+        self.dp, self.bucket = None, None      # data-parallel hook: (FlatDataParallel, bucket index)
 
     def flat_groups(self):
         """Parameter groups that must be laid out back to back in the flat buffer."""
         sfx = [''] + (['_reverse'] if self.nd == 2 else [])
-        return [[getattr(self.layer, n + s) for s in sfx] for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+        groups = [[getattr(self.layer, n + s) for s in sfx] for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+        if self.layer_norm:
+            groups += [[self.ln.weight], [self.ln.bias]]
+        if self.proj:
+            groups += [[self.pj.weight], [self.pj.bias]]
+        return groups
 
     def bind_flat(self, view_of):
         """view_of(params, shape, grad) -> tensor view over consecutive params."""

@@ -1,0 +1,36 @@
+"""One training step on the HIP path, shared by the Solver (bin/train_asr.py) and bench.py:
+forward -> CTC + attention losses -> backward -> [gradient all-reduce] -> global-norm clip + NaN guard
++ Adadelta, the sequence bin/train_asr.py:200-253 + src/solver.py:88-106 of the reference runs."""
+import torch
+
+
+def train_step(model, optimizer, ctc_crit, att_crit, feat, feat_len, txt, decode_step, tf_rate=1.0, dp=None,
+               clip=5.0, txt_len=None, optimize=True):
+    """Returns dict(total_loss, ctc_loss, att_loss, grad_normsq (device float64 scalar)).  No host sync."""
+    opt = optimizer.opt if hasattr(optimizer, 'opt') else optimizer
+    opt.zero_grad()
+    if txt_len is None:
+        txt_len = torch.sum(txt != 0, dim=-1)
+    ctc_output, encode_len, att_output, att_align, _ = model(feat, feat_len, decode_step, tf_rate=tf_rate, teacher=txt)
+    total, ctc_loss, att_loss = 0, None, None
+    if ctc_output is not None:
+        ctc_loss = ctc_crit(ctc_output.transpose(0, 1), txt, encode_len, txt_len)
+        total = total + ctc_loss * model.ctc_weight
+    if att_output is not None:
+        b, t, _ = att_output.shape
+        att_loss = att_crit(att_output.view(b * t, -1), txt[:, :t].reshape(-1))
+        w = (1 - model.ctc_weight)
+        if dp is not None and dp.world > 1:
+            w = w * dp.ce_weight(txt_len.sum())        # exact global token-mean under data parallelism
+        total = total + att_loss * w
+    total.backward()
+    grad_mul = 1.0
+    if dp is not None:
+        dp.finish()
+        grad_mul = dp.grad_mul
+    normsq = opt.grad_norm()
+    if optimize:
+        opt.step(clip=clip, grad_mul=grad_mul, use_norm=True)
+    return {'total_loss': total.detach(), 'ctc_loss': ctc_loss, 'att_loss': att_loss, 'grad_normsq': normsq,
+            'grad_mul': grad_mul, 'ctc_output': ctc_output, 'att_output': att_output, 'att_align': att_align,
+            'encode_len': encode_len}

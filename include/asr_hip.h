@@ -72,11 +72,17 @@ int asr_gemm(const float* A, const float* B, float* C, const float* bias,
  *   y     (B,T,ND*H) : h of both directions (forward half first);  c (B,T,ND,H): cell states
  * Backward consumes dy (gradient wrt y) and overwrites `gates` with the gradient wrt the gate
  * pre-activations, from which the caller forms dW_ih, dW_hh (shifted rows), db and dx with asr_gemm.
- * workspace: asr_lstm_bwd_workspace_bytes(B,H,ND), 16B aligned.
+ * workspace: asr_lstm_workspace_bytes(B,H,ND), 256B aligned.  With a workspace both passes run as ONE persistent
+ * launch each (weights resident in registers, h / partial-dh exchanged between workgroups through tagged
+ * granules in the workspace; its first 32-bit word is an abort flag that stays 0 on success); shapes without a
+ * persistent plan, a NULL workspace (forward) or ASR_LSTM_PERSIST=0 use one launch per time step.
  */
+size_t asr_lstm_workspace_bytes(int B, int H, int ND);
+/* 1 (default, or env ASR_LSTM_PERSIST) = persistent single-launch recurrence, 0 = one launch per step; returns the old value. */
+int asr_lstm_set_persistent(int on);
 int asr_lstm_fwd(float* gates, const float* whh, const float* bias2, float* y, float* c,
-                 int B, int T, int H, int ND, int prec, asr_stream_t stream);
-size_t asr_lstm_bwd_workspace_bytes(int B, int H, int ND);
+                 int B, int T, int H, int ND, int prec,
+                 void* workspace, size_t workspace_bytes, asr_stream_t stream);
 int asr_lstm_bwd(float* gates, const float* whh, const float* dy, const float* c,
                  int B, int T, int H, int ND, int prec,
                  void* workspace, size_t workspace_bytes, asr_stream_t stream);

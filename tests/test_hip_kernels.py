@@ -16,10 +16,21 @@ def _cuda(*ts):
     return [t.cuda() for t in ts]
 
 
+@pytest.mark.parametrize('persistent', [1, 0])
 @pytest.mark.parametrize('prec', [0, 1])
-@pytest.mark.parametrize('B,T,H,ND', [(3, 11, 16, 2), (5, 7, 20, 1), (18, 9, 32, 2), (16, 33, 320, 2)])
-def test_lstm_recurrence_fwd_bwd(B, T, H, ND, prec):
+@pytest.mark.parametrize('B,T,H,ND', [(3, 11, 16, 2), (5, 7, 20, 1), (18, 9, 32, 2), (16, 33, 320, 2), (33, 21, 128, 2), (7, 40, 64, 1)])
+def test_lstm_recurrence_fwd_bwd(B, T, H, ND, prec, persistent):
+    """persistent=1: single-launch recurrence with granule hand-offs (falls back by itself for H=20);
+    persistent=0: one launch per time step.  Both must match the oracle and leave the abort word at 0."""
     from src import hipabi as Hh
+    old = Hh.lib().asr_lstm_set_persistent(persistent)
+    try:
+        _lstm_case(Hh, B, T, H, ND, prec)
+    finally:
+        Hh.lib().asr_lstm_set_persistent(old)
+
+
+def _lstm_case(Hh, B, T, H, ND, prec):
     g = torch.Generator().manual_seed(B * 100 + T + H)
     Din = 12
     x = torch.randn(B, T, Din, generator=g)
@@ -48,13 +59,15 @@ def test_lstm_recurrence_fwd_bwd(B, T, H, ND, prec):
     y = torch.empty(B, T, ND * H, device='cuda')
     c = torch.empty(B, T, ND, H, device='cuda')
     st = Hh.stream_ptr()
-    Hh.call('asr_lstm_fwd', Hh.ptr(gates), Hh.ptr(whh), Hh.ptr(bhh), Hh.ptr(y), Hh.ptr(c), B, T, H, ND, prec, st)
+    nbytes = Hh.lib().asr_lstm_workspace_bytes(B, H, ND)
+    ws = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device='cuda')     # poisoned: the call must re-initialise it
+    Hh.call('asr_lstm_fwd', Hh.ptr(gates), Hh.ptr(whh), Hh.ptr(bhh), Hh.ptr(y), Hh.ptr(c), B, T, H, ND, prec, Hh.ptr(ws), nbytes, st)
     tol = 2e-5 if prec == 0 else 3e-2
     assert (y.cpu() - y_ref.detach()).abs().max().item() < tol
-    nbytes = Hh.lib().asr_lstm_bwd_workspace_bytes(B, H, ND)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
     dyd = dy.cuda()
     Hh.call('asr_lstm_bwd', Hh.ptr(gates), Hh.ptr(whh), Hh.ptr(dyd), Hh.ptr(c), B, T, H, ND, prec, Hh.ptr(ws), nbytes, st)
+    flag = int(ws[:4].view(torch.int32).item())
+    assert flag in (0, 0x5A5A5A5A), 'persistent LSTM kernel raised its abort word: %x' % flag
     # dx and dW from the pre-activation gradients
     dx = torch.empty(B, T, Din, device='cuda')
     g2 = gates.view(B * T, G)

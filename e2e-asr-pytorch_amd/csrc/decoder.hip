@@ -14,7 +14,8 @@
 
 namespace {
 
-constexpr int TT = 64;  // encoder frames per workgroup in the energy kernels
+constexpr int TT = 16;   // encoder frames per workgroup in the energy kernels (4 waves x TPW frames)
+constexpr int TPW = TT / 4;
 
 // tanh via one v_exp: 1 - 2/(1+e^{2x}); absolute error ~1e-7 (the energy kernels evaluate ~6 M of these per step)
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
@@ -97,19 +98,15 @@ __device__ __forceinline__ void conv_tile(const DecP& p, int b, int t, int tau0,
     }
     for (int i = threadIdx.x; i < d.Kn * taps; i += blockDim.x) s_wc[i] = p.w.Wconv[i];
     __syncthreads();
-    // each thread produces 4 consecutive frames of one kernel with a sliding register window
-    for (int o = threadIdx.x; o < d.Kn * (TT / 4); o += blockDim.x) {
-        const int i0 = (o % (TT / 4)) * 4, k = o / (TT / 4);
+    // one (frame, kernel) output per thread
+    for (int o = threadIdx.x; o < d.Kn * TT; o += blockDim.x) {
+        const int i = o % TT, k = o / TT;
         const float* wk = s_wc + k * taps;
-        float w0 = s_pa[i0], w1 = s_pa[i0 + 1], w2 = s_pa[i0 + 2];
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int j = 0; j < taps; ++j) {
-            const float w3 = s_pa[i0 + j + 3 < win ? i0 + j + 3 : win - 1];
-            const float c = wk[j];
-            a0 += c * w0; a1 += c * w1; a2 += c * w2; a3 += c * w3;
-            w0 = w1; w1 = w2; w2 = w3;
-        }
-        s_conv[k * TT + i0] = a0; s_conv[k * TT + i0 + 1] = a1; s_conv[k * TT + i0 + 2] = a2; s_conv[k * TT + i0 + 3] = a3;
+        float a0 = 0.f, a1 = 0.f;
+        int j = 0;
+        for (; j + 1 < taps; j += 2) { a0 += wk[j] * s_pa[i + j]; a1 += wk[j + 1] * s_pa[i + j + 1]; }
+        if (j < taps) a0 += wk[j] * s_pa[i + j];
+        s_conv[o] = a0 + a1;
     }
     __syncthreads();
 }
@@ -130,24 +127,24 @@ __global__ __launch_bounds__(256) void att_energy_kernel(DecP p, int t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int len = (int)p.enc_len[b];
     const float* qrow = p.s.q + ((long)b * d.L + t) * d.A;
-    float e[16];
+    float e[TPW];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) e[i] = 0.f;
+    for (int i = 0; i < TPW; ++i) e[i] = 0.f;
     const int tmax = max(min(len, d.Tp) - 1, 0);
     for (int a = lane; a < d.A; a += 64) {
         float wp[KNMAX];
 #pragma unroll
         for (int k = 0; k < KNMAX; ++k) wp[k] = (k < d.Kn) ? p.w.Wproj[(long)a * d.Kn + k] : 0.f;
         const float qa = qrow[a], wga = p.w.wg[a];
-        float kv[16];
+        float kv[TPW];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {   // all 16 key loads of this column in flight together
-            const int tau = min(tau0 + wave * 16 + i, tmax);
+        for (int i = 0; i < TPW; ++i) {   // all key loads of this column in flight together
+            const int tau = min(tau0 + wave * TPW + i, tmax);
             kv[i] = p.s.key[((long)b * d.Tp + tau) * d.A + a];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ti = wave * 16 + i;
+        for (int i = 0; i < TPW; ++i) {
+            const int ti = wave * TPW + i;
             float lp = 0.f;
 #pragma unroll
             for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
@@ -156,9 +153,9 @@ __global__ __launch_bounds__(256) void att_energy_kernel(DecP p, int t) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < TPW; ++i) {
         const float s = wave_sum(e[i]);
-        const int tau = tau0 + wave * 16 + i;
+        const int tau = tau0 + wave * TPW + i;
         if (lane == 0 && tau < d.Tp)
             p.s.energy[(long)b * d.Tp + tau] = (tau < len) ? (s + p.w.bg[0]) / d.temperature : -INFINITY;
     }
@@ -261,9 +258,12 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(DecP p, int t) {
 // gate n>>2 of hidden unit 4*blockIdx.x + (n&3).
 // ------------------------------------------------------------------------------------------------
 template <bool BF16>
-__global__ __launch_bounds__(64) void dec_cell_fwd_kernel(DecP p, int t, int l) {
+__global__ __launch_bounds__(256) void dec_cell_fwd_kernel(DecP p, int t, int l) {
+    // block = 4 hidden units x 4 gates (16 columns); the K = Kx + Dd reduction is split over the 4 waves
+    // (interleaved k-steps) and summed through LDS, so one memory round trip per wave covers ~K/4.
+    __shared__ float red[4][256];
     const asr_dec_dims_t& d = p.d;
-    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
     const int g = n >> 2;
     const int j = blockIdx.x * 4 + (n & 3);
     const bool jok = j < d.Dd;
@@ -271,7 +271,6 @@ __global__ __launch_bounds__(64) void dec_cell_fwd_kernel(DecP p, int t, int l) 
     const int Kx = (l == 0) ? XW : d.Dd;
     const float* wih = p.w.Wih[l] + ((long)g * d.Dd + (jok ? j : 0)) * Kx;
     const float* whh = p.w.Whh[l] + ((long)g * d.Dd + (jok ? j : 0)) * d.Dd;
-    const int base = lane & ~12;
     const long SW = (long)d.NL * d.Dd;  // row width of hs/cs
     for (int m0 = 0; m0 < d.B; m0 += 16) {
         const int ab = m0 + n;
@@ -279,28 +278,36 @@ __global__ __launch_bounds__(64) void dec_cell_fwd_kernel(DecP p, int t, int l) 
         const long rowi = (long)(rok ? ab : 0) * d.L + t;
         const float* xrow = (l == 0) ? p.s.xin + rowi * XW : p.s.hs + rowi * SW + (long)(l - 1) * d.Dd;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = dot_rows<BF16>(xrow, rok, wih, jok, Kx, 0, 1, (Kx % 4) == 0 && (d.Dd % 4) == 0, acc);
+        acc = dot_rows<BF16>(xrow, rok, wih, jok, Kx, wave, 4, (Kx % 4) == 0 && (d.Dd % 4) == 0, acc);
         if (t > 0) {
             const float* hrow = p.s.hs + (rowi - 1) * SW + (long)l * d.Dd;
-            acc = dot_rows<BF16>(hrow, rok, whh, jok, d.Dd, 0, 1, (d.Dd % 4) == 0, acc);
+            acc = dot_rows<BF16>(hrow, rok, whh, jok, d.Dd, wave, 4, (d.Dd % 4) == 0, acc);
         }
-        const float bias = jok ? (p.w.bih[l][g * d.Dd + j] + p.w.bhh[l][g * d.Dd + j]) : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = m0 + 4 * q + r;
-            const bool ok = jok && b < d.B;
-            const float pre = acc[r] + bias;
-            const float a = (g == 2) ? tanhf(pre) : sigmoidf_(pre);
-            const long ri = (long)(ok ? b : 0) * d.L + t;
-            if (ok) p.s.gates[(ri * d.NL + l) * 4 * d.Dd + g * d.Dd + j] = a;
-            const float ai = __shfl(a, base), af = __shfl(a, base + 4), ag = __shfl(a, base + 8), ao = __shfl(a, base + 12);
-            if (ok && g == 0) {
-                const float cp = (t > 0) ? p.s.cs[(ri - 1) * SW + (long)l * d.Dd + j] : 0.f;
+        for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
+        __syncthreads();
+        if (tid < 64) {
+            // thread (row, unit): gathers its four gate columns
+            const int row = tid >> 2, jj = tid & 3;
+            const int b = m0 + row, ju = blockIdx.x * 4 + jj;
+            if (b < d.B && ju < d.Dd) {
+                float pre[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int c = row * 16 + gg * 4 + jj;
+                    pre[gg] = red[0][c] + red[1][c] + red[2][c] + red[3][c] + p.w.bih[l][gg * d.Dd + ju] + p.w.bhh[l][gg * d.Dd + ju];
+                }
+                const float ai = sigmoidf_(pre[0]), af = sigmoidf_(pre[1]), ag = tanhf(pre[2]), ao = sigmoidf_(pre[3]);
+                const long ri = (long)b * d.L + t;
+                float* go = p.s.gates + (ri * d.NL + l) * 4 * d.Dd;
+                go[ju] = ai; go[d.Dd + ju] = af; go[2 * d.Dd + ju] = ag; go[3 * d.Dd + ju] = ao;
+                const float cp = (t > 0) ? p.s.cs[(ri - 1) * SW + (long)l * d.Dd + ju] : 0.f;
                 const float cn = af * cp + ai * ag;
-                p.s.cs[ri * SW + (long)l * d.Dd + j] = cn;
-                p.s.hs[ri * SW + (long)l * d.Dd + j] = ao * tanhf(cn);
+                p.s.cs[ri * SW + (long)l * d.Dd + ju] = cn;
+                p.s.hs[ri * SW + (long)l * d.Dd + ju] = ao * tanhf(cn);
             }
         }
+        __syncthreads();
     }
 }
 
@@ -425,8 +432,8 @@ __global__ __launch_bounds__(256) void att_bwd_dattn_kernel(DecB p, int t, int l
     for (int i = threadIdx.x; i < d.E; i += 256) smem_f[i] = dctx[i];
     __syncthreads();
     const int tmax = max(len - 1, 0);
-    for (int i0 = 0; i0 < 16; i0 += 4) {
-        const int tb = tau0 + wave * 16 + i0;
+    for (int i0 = 0; i0 < TPW; i0 += 4) {
+        const int tb = tau0 + wave * TPW + i0;
         if (tb >= d.Tp) break;
         const float* r0 = p.f.enc + ((long)b * d.Tp + min(tb, tmax)) * d.E;
         const float* r1 = p.f.enc + ((long)b * d.Tp + min(tb + 1, tmax)) * d.E;
@@ -492,16 +499,16 @@ __global__ __launch_bounds__(256) void att_bwd_energy_kernel(DecB p, int t) {
         for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? p.f.w.Wproj[(long)a * d.Kn + k] : 0.f; dwp[k] = 0.f; }
         const float qa = qrow[a], wga = p.f.w.wg[a];
         float dwg = 0.f, dqa = 0.f;
-        float kv[16], dk[16];
+        float kv[TPW], dk[TPW];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {   // key and dkey of this column: 32 loads in flight
-            const long ki = ((long)b * d.Tp + min(tau0 + wave * 16 + i, tmax)) * d.A + a;
+        for (int i = 0; i < TPW; ++i) {   // key and dkey of this column in flight together
+            const long ki = ((long)b * d.Tp + min(tau0 + wave * TPW + i, tmax)) * d.A + a;
             kv[i] = p.f.s.key[ki];
             dk[i] = p.dkey[ki];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ti = wave * 16 + i;
+        for (int i = 0; i < TPW; ++i) {
+            const int ti = wave * TPW + i;
             const int tau = tau0 + ti;
             float lp = 0.f;
 #pragma unroll
@@ -565,12 +572,13 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(DecB p, int t) {
     __syncthreads();
     // conv[k][tau] = sum_j W[k][j] pa[tau + j - Ks]  =>  d pa[tau'] = sum_k sum_j W[k][j] dconv[k][tau' - j + Ks]
     // 4 thread groups split the kernels k; partial sums meet in LDS
-    __shared__ float s_red[4][TT];
+    __shared__ float s_red[256 / TT][TT];
     {
-        const int i = threadIdx.x & 63, kg = threadIdx.x >> 6;
+        constexpr int NKG = 256 / TT;
+        const int i = threadIdx.x % TT, kg = threadIdx.x / TT;
         float acc = 0.f;
         if (t > 0) {
-            for (int k = kg; k < d.Kn; k += 4) {
+            for (int k = kg; k < d.Kn; k += NKG) {
                 const float* wk = s_wc + k * taps;
                 const float* dc = s_dc + k * win + i + 2 * d.Ks;   // window index of tau' + Ks
                 for (int j = 0; j < taps; ++j) acc += wk[j] * dc[-j];
@@ -582,7 +590,12 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(DecB p, int t) {
     if (t > 0 && threadIdx.x < TT) {
         const int tau = tau0 + threadIdx.x;
         if (tau < d.Tp)
-            p.datt_next[(long)b * d.Tp + tau] = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 256 / TT; ++g) v += s_red[g][threadIdx.x];
+            p.datt_next[(long)b * d.Tp + tau] = v;
+        }
     }
     // d W_conv[k][j] += sum_{tau in tile} dconv[k][tau] * pa[tau + j - Ks]
     float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot + d.A * (1 + d.Kn) + 1;
@@ -735,8 +748,8 @@ extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_wei
         else                 hipLaunchKernelGGL(att_energy_kernel<16>, grid_tile, dim3(256), lds_energy, st, p, t);
         hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
         for (int l = 0; l < d.NL; ++l) {
-            if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(64), 0, st, p, t, l);
-            else    hipLaunchKernelGGL(dec_cell_fwd_kernel<false>, dim3(cdiv(d.Dd, 4)), dim3(64), 0, st, p, t, l);
+            if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
+            else    hipLaunchKernelGGL(dec_cell_fwd_kernel<false>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
         }
         if (!teacher) hipLaunchKernelGGL(dec_greedy_kernel, dim3(d.B), dim3(256), sizeof(float) * d.V, st, p, t);
     }

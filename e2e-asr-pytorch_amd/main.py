@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Entry point with the reference's command line (main.py:12-106): `python main.py --config X [--test] ...`.
+Under torchrun (WORLD_SIZE > 1) each process drives one GPU and gradients are all-reduced over RCCL."""
+import argparse
+import random
+
+import numpy as np
+import torch
+import yaml
+
+parser = argparse.ArgumentParser(description='Training E2E asr (MI355X HIP path).')
+parser.add_argument('--config', type=str, help='Path to experiment config.')
+parser.add_argument('--name', default=None, type=str)
+parser.add_argument('--logdir', default='log/', type=str)
+parser.add_argument('--ckpdir', default='ckpt/', type=str)
+parser.add_argument('--outdir', default='result/', type=str)
+parser.add_argument('--load', default=None, type=str)
+parser.add_argument('--seed', default=0, type=int)
+parser.add_argument('--cudnn-ctc', action='store_true', help='accepted for compatibility; the HIP CTC kernel is always used')
+parser.add_argument('--njobs', default=4, type=int)
+parser.add_argument('--cpu', action='store_true', help='not supported: the HIP path has no CPU fallback')
+parser.add_argument('--no-pin', action='store_true')
+parser.add_argument('--test', action='store_true')
+parser.add_argument('--no-msg', action='store_true')
+parser.add_argument('--lm', action='store_true')
+parser.add_argument('--amp', action='store_true', help='accepted for compatibility; precision is chosen by hip.prec in the YAML')
+parser.add_argument('--cuda', default=0, type=int)
+parser.add_argument('--deterministic', action='store_true')
+parser.add_argument('--upstream', default=None)
+
+
+def main():
+    paras = parser.parse_args()
+    setattr(paras, 'gpu', not paras.cpu)
+    setattr(paras, 'pin_memory', not paras.no_pin)
+    setattr(paras, 'verbose', not paras.no_msg)
+    config = yaml.load(open(paras.config, 'r'), Loader=yaml.FullLoader)
+    from src import dist as D_
+    rank, world, local = D_.init_from_env()
+    if world > 1:
+        paras.cuda = local
+        paras.verbose = paras.verbose and rank == 0
+    random.seed(paras.seed)
+    np.random.seed(paras.seed)
+    torch.manual_seed(paras.seed)
+    if paras.lm:
+        raise NotImplementedError('RNN-LM training is outside the hot path of this build')
+    if paras.test:
+        from bin.test_asr import Solver
+        mode = 'test'
+    else:
+        from bin.train_asr import Solver
+        mode = 'train'
+    solver = Solver(config, paras, mode)
+    solver.load_data()
+    solver.set_model()
+    solver.exec()
+
+
+if __name__ == '__main__':
+    main()

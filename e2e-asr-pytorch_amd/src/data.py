@@ -1,0 +1,50 @@
+"""Batch source with the reference's contract (src/data.py:104-143, src/collect_batch.py:10-48):
+iterables yielding (file_names, feat (B,T,D) fp32 zero-padded, feat_len (B) int64 descending,
+txt (B,L) int64 0-padded, each row ending in <eos>=1).
+
+No corpus can be read offline (FLAC decoding and the LibriSpeech tree are outside this build, SURVEY
+§8f-2), so `corpus.path: 'synthetic'` (or a missing path) selects LibriSpeech-shaped random batches with
+the bucketing + batch-halving rule of the reference (HALF_BATCHSIZE_AUDIO_LEN = 800 frames)."""
+import os
+
+import numpy as np
+import torch
+
+from src.synthetic import librispeech_shaped_batch
+from src.text import load_text_encoder
+
+HALF_BATCHSIZE_AUDIO_LEN = 800
+
+
+class SyntheticLoader(object):
+    def __init__(self, n_batches, batch_size, feat_dim, vocab_size, seed, train, max_frames=2450):
+        self.n, self.bs, self.D, self.V, self.seed, self.train, self.maxT = n_batches, batch_size, feat_dim, vocab_size, seed, train, max_frames
+
+    def __len__(self):
+        return self.n * self.bs
+
+    def __iter__(self):
+        g = np.random.Generator(np.random.PCG64(self.seed))
+        for i in range(self.n):
+            T = int(np.clip(round(g.normal(1270, 480)), 150, self.maxT))
+            B = self.bs // 2 if (self.train and T > HALF_BATCHSIZE_AUDIO_LEN) else self.bs
+            L = int(np.clip(round(T * 0.14), 5, 400))
+            feat, flen, txt = librispeech_shaped_batch(B, T, self.D, L, self.V, seed=self.seed * 7919 + i)
+            yield ['synthetic-%d-%d' % (i, b) for b in range(B)], feat, flen, txt
+
+
+def load_dataset(n_jobs, use_gpu, pin_memory, ascending, corpus, audio, text):
+    tokenizer = load_text_encoder(**text)
+    feat_dim = audio['feat_dim'] * (audio.get('delta_order', 0) + 1)
+    path = corpus.get('path', 'synthetic')
+    if path != 'synthetic' and os.path.isdir(path):
+        raise NotImplementedError('reading LibriSpeech from disk (FLAC) is outside the HIP hot-path build; '
+                                  "set data.corpus.path: 'synthetic'")
+    bs = corpus['batch_size']
+    n_tr = corpus.get('subset', 2000) // bs
+    tr = SyntheticLoader(max(n_tr, 1), bs, feat_dim, tokenizer.vocab_size, seed=1, train=True)
+    dv = SyntheticLoader(4, bs, feat_dim, tokenizer.vocab_size, seed=2, train=False, max_frames=1200)
+    msg = ['Data spec. | Corpus = synthetic LibriSpeech-shaped batches (no corpus on disk)',
+           'I/O spec.  | Audio Feature = {}\t| Feature Dim = {}\t| Token Type = {}\t| Vocab Size = {}'.format(
+               audio['feat_type'], feat_dim, tokenizer.token_type, tokenizer.vocab_size)]
+    return tr, dv, feat_dim, tokenizer.vocab_size, tokenizer, msg

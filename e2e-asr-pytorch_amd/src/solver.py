@@ -1,0 +1,138 @@
+"""BaseSolver with the reference's surface (src/solver.py:12-240): device pick, checkpoint / log dirs,
+`backward`, `load_ckpt`, `save_checkpoint`, `write_log`, `verbose`, `progress`.
+
+Differences forced by the HIP path: `backward` leaves the global-norm clip and the NaN guard to the fused
+optimizer kernel (device-side, no host sync) and all-reduces the flat gradient first when data-parallel;
+TensorBoard is replaced by a JSONL scalar log when `tensorboard` is not installed."""
+import json
+import math
+import os
+import sys
+
+import torch
+
+from src.option import default_hparas
+from src.util import human_format, Timer
+
+
+class _JsonlWriter(object):
+    def __init__(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        self.f = open(os.path.join(logdir, 'scalars.jsonl'), 'a')
+
+    def add_scalars(self, name, d, step):
+        self.f.write(json.dumps({'name': name, 'step': step, 'values': {k: float(v) for k, v in d.items()}}) + '\n')
+        self.f.flush()
+
+    def add_text(self, name, text, step):
+        self.f.write(json.dumps({'name': name, 'step': step, 'text': text}) + '\n')
+
+    def add_image(self, *a, **k):
+        pass
+
+    add_audio = add_image
+
+    def close(self):
+        self.f.close()
+
+
+class BaseSolver():
+    def __init__(self, config, paras, mode):
+        self.config, self.paras, self.mode = config, paras, mode
+        for k, v in default_hparas.items():
+            setattr(self, k, v)
+        if not (self.paras.gpu and torch.cuda.is_available()):
+            raise RuntimeError('the HIP path needs an MI355X (gfx950) device; there is no CPU fallback')
+        self.device = torch.device('cuda:' + str(paras.cuda))
+        self.amp = getattr(paras, 'amp', False)
+        self.exp_name = paras.name
+        if self.exp_name is None:
+            self.exp_name = paras.config.split('/')[-1].replace('.yaml', '')
+            if mode == 'train':
+                self.exp_name += '_sd{}'.format(paras.seed)
+        self.emb_decoder = None
+        self.transfer_learning = False
+        self.dp = None
+        if mode == 'train':
+            os.makedirs(paras.ckpdir, exist_ok=True)
+            self.ckpdir = os.path.join(paras.ckpdir, self.exp_name)
+            os.makedirs(self.ckpdir, exist_ok=True)
+            self.logdir = os.path.join(paras.logdir, self.exp_name)
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.log = SummaryWriter(self.logdir, flush_secs=self.TB_FLUSH_FREQ)
+            except Exception:
+                self.log = _JsonlWriter(self.logdir)
+            self.timer = Timer()
+            self.step = 0
+            self.valid_step = config['hparas']['valid_step']
+            self.max_step = config['hparas']['max_step']
+            self.verbose('Exp. name : {}'.format(self.exp_name))
+
+    def backward(self, loss, time_cnt=True, optimize=True):
+        """loss.backward(); gradient all-reduce (DP); clip-by-global-norm + NaN guard + optimizer step on the
+        device (reference src/solver.py:88-106).  Returns the gradient norm as a 0-dim device tensor."""
+        if time_cnt:
+            self.timer.set()
+        loss.backward()
+        opt = self.optimizer.opt
+        grad_mul = 1.0
+        if self.dp is not None:
+            self.dp.finish()
+            grad_mul = self.dp.grad_mul
+        normsq = opt.grad_norm()
+        if optimize:
+            opt.step(clip=self.GRAD_CLIP, grad_mul=grad_mul, use_norm=True)
+        if time_cnt:
+            self.timer.cnt('bw')
+        return normsq.sqrt().float().reshape(()) * grad_mul
+
+    def load_ckpt(self):
+        if self.paras.load:
+            ckpt = torch.load(self.paras.load, map_location=self.device)
+            self.model.load_state_dict(ckpt['model'])
+            if self.mode == 'train':
+                self.step = ckpt['global_step']
+                try:
+                    self.optimizer.load_opt_state_dict(ckpt['optimizer'])
+                except Exception as e:   # a checkpoint written by another optimizer implementation
+                    self.verbose('optimizer state not restored: {}'.format(e))
+                self.verbose('Load ckpt from {}, restarting at step {}'.format(self.paras.load, self.step))
+            else:
+                metric, score = None, None
+                for k, v in ckpt.items():
+                    if type(v) is float:
+                        metric, score = k, v
+                self.model.eval()
+                self.verbose('Evaluation target = {} (recorded {} = {:.2f} %)'.format(self.paras.load, metric, (score or 0) * 100))
+
+    def verbose(self, msg):
+        if self.paras.verbose:
+            for m in (msg if type(msg) == list else [msg]):
+                print('[INFO]', m.ljust(100))
+
+    def progress(self, msg):
+        if self.paras.verbose:
+            sys.stdout.write("\033[K")
+            print('[{}] {}'.format(human_format(self.step), msg), end='\r')
+
+    def write_log(self, log_name, log_dict):
+        if type(log_dict) is dict:
+            log_dict = {k: (v.item() if torch.is_tensor(v) else v) for k, v in log_dict.items() if v is not None}
+            log_dict = {k: v for k, v in log_dict.items() if not math.isnan(v)}
+        if log_dict is None:
+            return
+        if len(log_dict) > 0:
+            if 'align' in log_name or 'spec' in log_name:
+                return
+            elif 'text' in log_name or 'hyp' in log_name:
+                self.log.add_text(log_name, log_dict, self.step)
+            else:
+                self.log.add_scalars(log_name, log_dict, self.step)
+
+    def save_checkpoint(self, f_name, metric, score, name=''):
+        ckpt_path = os.path.join(self.ckpdir, f_name)
+        torch.save({'model': self.model.state_dict(), 'optimizer': self.optimizer.get_opt_state_dict(),
+                    'global_step': self.step, metric: score}, ckpt_path)
+        self.verbose('Saved ckpt (step = {}, {} = {:.2f}) @ {}{}'.format(
+            human_format(self.step), metric, score, ckpt_path, (' on ' + name) if name else ''))

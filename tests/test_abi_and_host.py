@@ -1,0 +1,122 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/asr_hip.h declares, the host
+mirror keeps the reference's parameter names/shapes and batch contract, and the product path refuses to
+run without a GPU (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import asr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'e2e-asr-pytorch_amd')
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'asr_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(asr_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib_path = os.path.join(PKG, 'lib', 'libasr_hip.so')
+    assert os.path.exists(lib_path), 'run `python -c "import __graft_entry__ as g; g.build()"` first'
+    lib = ctypes.CDLL(lib_path)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), 'missing export: ' + n
+    lib.asr_device_arch.restype = ctypes.c_char_p
+    assert lib.asr_device_arch() == b'gfx950'
+
+
+def test_ctypes_binding_covers_the_header():
+    from src import hipabi
+    assert set(declared_symbols()) == set(hipabi.exported_symbols())
+
+
+@pytest.mark.parametrize('cfg_name', ['librispeech_asr.yaml', 'debug.yaml'])
+def test_state_dict_matches_reference_layout(cfg_name):
+    from src.asr import ASR
+    config = yaml.safe_load(open(os.path.join(PKG, 'config', cfg_name)))
+    D = config['data']['audio']['feat_dim'] * (config['data']['audio']['delta_order'] + 1)
+    model = ASR(D, 31, 8, **config['model'])
+    shapes = O.param_shapes(O.ModelCfg(config['model'], D, 31))
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    for k, s in shapes.items():
+        assert tuple(sd[k].shape) == tuple(s), k
+    if cfg_name == 'librispeech_asr.yaml':
+        assert sum(p.numel() for p in model.parameters()) == 12079853
+    # init end state: biases zero except the decoder forget-gate slice
+    for k, v in sd.items():
+        if v.dim() == 1 and 'decoder.layers.bias_ih' not in k:
+            assert float(v.abs().max()) == 0.0, k
+    b = sd['decoder.layers.bias_ih_l0']
+    n = b.numel()
+    assert float(b[n // 4:n // 2].min()) == 1.0 and float(b[:n // 4].abs().max()) == 0.0
+    # all parameters are views of ONE flat buffer, gradients of another
+    base = model.flat_param.data_ptr()
+    for p in model.parameters():
+        assert base <= p.data_ptr() < base + model.flat_param.numel() * 4
+        assert p.grad is not None and p.grad.shape == p.shape
+    # RNN layers expose concatenated (both-direction) views that alias the per-direction parameters
+    l0 = model.encoder.layers[-1]
+    assert l0.w_ih_cat.shape[0] == 2 * 4 * l0.dim
+    assert l0.w_ih_cat[4 * l0.dim].data_ptr() == l0.layer.weight_ih_l0_reverse.data_ptr()
+
+
+def test_product_path_has_no_cpu_fallback():
+    from src.asr import ASR
+    config = yaml.safe_load(open(os.path.join(PKG, 'config', 'debug.yaml')))
+    model = ASR(120, 31, 8, **config['model'])
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 40, 120), torch.tensor([40, 30]), 5)
+    # nothing under the package may import the oracle
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith('.py'):
+                assert 'oracle' not in open(os.path.join(dirpath, f)).read(), os.path.join(dirpath, f)
+
+
+def test_tokenizer_and_batch_contract():
+    from src.data import load_dataset
+    from src.text import load_text_encoder
+    tok = load_text_encoder('character', os.path.join(PKG, 'corpus', 'librispeech_char.txt'))
+    assert tok.vocab_size == 31
+    ids = tok.encode("HELLO WORLD'S\n")
+    assert ids[-1] == 1 and tok.decode(ids) == "HELLO WORLD'S"
+    assert tok.decode([5, 5, 0, 6, 6, 1, 7], ignore_repeat=True) == tok.decode([5, 6])
+    config = yaml.safe_load(open(os.path.join(PKG, 'config', 'librispeech_asr.yaml')))
+    config['data']['corpus']['path'] = 'synthetic'
+    config['data']['text']['vocab_file'] = os.path.join(PKG, 'corpus', 'librispeech_char.txt')
+    tr, dv, feat_dim, V, tokenizer, msg = load_dataset(0, False, False, False, **config['data'])
+    assert feat_dim == 160 and V == 31
+    names, feat, flen, txt = next(iter(tr))
+    B, T, D = feat.shape
+    assert D == 160 and flen.dtype == torch.int64 and txt.dtype == torch.int64
+    assert B in (8, 16) and (B == 8) == (T > 800)              # batch halving rule, src/collect_batch.py:21-24
+    assert int(flen[0]) == T and bool((flen[:-1] >= flen[1:]).all())
+    for b in range(B):
+        assert float(feat[b, int(flen[b]):].abs().sum()) == 0.0
+        tl = int((txt[b] != 0).sum())
+        assert int(txt[b, tl - 1]) == 1 and bool((txt[b, tl:] == 0).all())
+
+
+def test_optimizer_schedule_and_state_layout():
+    from src.asr import ASR
+    from src.optim import Optimizer
+    config = yaml.safe_load(open(os.path.join(PKG, 'config', 'debug.yaml')))
+    model = ASR(120, 31, 8, **config['model'])
+    opt = Optimizer(model.parameters(), 'Adadelta', 1.0, 1e-8, 'fixed', tf_start=1.0, tf_end=0.5, tf_step=100)
+    assert opt.tf_rate(0) == 1.0 and abs(opt.tf_rate(50) - 0.75) < 1e-9 and opt.tf_rate(1000) == 0.5
+    sd = opt.get_opt_state_dict()
+    assert len(sd['state']) == len(list(model.parameters()))
+    st0 = sd['state'][0]
+    assert set(st0.keys()) >= {'square_avg', 'acc_delta'}
+    with pytest.raises(NotImplementedError):
+        Optimizer(model.parameters(), 'SGD', 1.0, 1e-8)

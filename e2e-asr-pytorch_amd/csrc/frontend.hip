@@ -1,0 +1,199 @@
+// Acoustic front-end on the GPU, batched over utterances (the reference runs it per file on CPU workers):
+//   asr_fbank       : ExtractAudioFeature.forward (src/audio.py:158-171,231-244): pre-emphasis -> STFT
+//                     (n_fft 1025, hann 400 centred, hop 160, center + reflect pad) -> |.| -> mel (80 x 513)
+//                     -> 20 log10(max(x,1e-5)) - ref_db -> clamp((x - min_db) / -min_db, 0, 1)
+//                     The DFT is a contraction of the 400 windowed samples of each frame with a (1026 x 400)
+//                     cos/-sin table (exact fp32 MFMA), the mel projection a second contraction.
+//   asr_delta_stack : Delta (src/audio.py:59-93) + Postprocess (:108-121): cross-correlation along time with
+//                     the order-k delta filters, zero padding at the utterance ends, channel-major stacking.
+//   asr_specaug     : Augment (src/audio.py:364-406): one time mask and one frequency mask per utterance,
+//                     filled with the mean (recomputed after the time mask), in place on the padded batch.
+#include "common.h"
+
+namespace {
+
+// frames[(b*T + k), m] = hann[m] * y_b[reflect(k*hop + (n_fft-win)/2 + m - n_fft/2)],  y = pre-emphasised wave
+__global__ void frame_kernel(const float* __restrict__ wav, const int64_t* __restrict__ wav_len, float* __restrict__ frames,
+                             const float* __restrict__ window, int B, int N, int T, int win, int hop, int n_fft, float preemph) {
+    const long total = (long)B * T * win;
+    const int off = (n_fft - win) / 2 - n_fft / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % win);
+        const int k = (int)((i / win) % T);
+        const int b = (int)(i / ((long)win * T));
+        const int n = (int)wav_len[b];
+        float v = 0.f;
+        if (n > 1 && k < 1 + (n - 1) / hop) {   // center padding n_fft/2 each side with odd n_fft: 1 + (n-1)/hop frames
+            int p = k * hop + off + m;
+            if (p < 0) p = -p;
+            if (p >= n) p = 2 * (n - 1) - p;
+            p = max(0, min(p, n - 1));
+            const float* x = wav + (long)b * N;
+            const float y = (p == 0) ? x[0] : x[p] - preemph * x[p - 1];
+            v = window[m] * y;
+        }
+        frames[i] = v;
+    }
+}
+
+__global__ void magnitude_kernel(const float* __restrict__ spec, float* __restrict__ mag, long rows, int nbins) {
+    // spec: (rows, 2*nbins) = [re | im]
+    const long total = rows * nbins;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / nbins;
+        const int f = (int)(i % nbins);
+        const float re = spec[r * 2 * nbins + f], im = spec[r * 2 * nbins + nbins + f];
+        mag[i] = sqrtf(re * re + im * im);
+    }
+}
+
+__global__ void logmel_kernel(float* __restrict__ mel, const int64_t* __restrict__ wav_len, long rows, int T, int nmel, int hop,
+                              float ref_db, float min_db) {
+    const long total = rows * nmel;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / nmel;
+        const int b = (int)(r / T), k = (int)(r % T);
+        float v = 0.f;
+        if (k < 1 + ((int)wav_len[b] - 1) / hop) {
+            const float db = 20.f * log10f(fmaxf(mel[i], 1e-5f)) - ref_db;
+            v = fminf(fmaxf((db - min_db) / -min_db, 0.f), 1.f);
+        }
+        mel[i] = v;   // frames beyond the utterance are zero padding
+    }
+}
+
+// out[b,t,c*F+f] = sum_j filt[c][j] * x[b, t + j - pad, f], zero outside [0, len_b)
+__global__ void delta_stack_kernel(const float* __restrict__ x, const int64_t* __restrict__ lens, float* __restrict__ out,
+                                   const float* __restrict__ filt, int B, int T, int F, int C, int taps) {
+    const long total = (long)B * T * C * F;
+    const int pad = (taps - 1) / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const int c = (int)((i / F) % C);
+        const int t = (int)((i / ((long)F * C)) % T);
+        const int b = (int)(i / ((long)F * C * T));
+        const int len = (int)lens[b];
+        float acc = 0.f;
+        if (t < len) {
+            for (int j = 0; j < taps; ++j) {
+                const int tt = t + j - pad;
+                if (tt >= 0 && tt < len) acc += filt[c * taps + j] * x[((long)b * T + tt) * F + f];
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+// SpecAugment: one workgroup per utterance.  draws[b] = {t, t0, tend, f, f0, fend} (reference draw order).
+__global__ __launch_bounds__(1024) void specaug_kernel(float* __restrict__ x, const int64_t* __restrict__ lens,
+                                                       const int* __restrict__ draws_in, int* __restrict__ draws_out,
+                                                       int B, int T, int D, int Tmask, int Fmask, uint64_t seed) {
+    __shared__ double s_red[16];
+    __shared__ int s_draw[6];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int len = min((int)lens[b], T);
+    float* xb = x + (long)b * T * D;
+    if (tid == 0) {
+        int dr[6];
+        if (draws_in) {
+            for (int i = 0; i < 6; ++i) dr[i] = draws_in[b * 6 + i];
+        } else {
+            uint32_t r[4], r2[4];
+            philox4x32((uint32_t)b, 0u, 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            philox4x32((uint32_t)b, 0u, 2u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r2);
+            const int t = (int)(r[0] % (uint32_t)Tmask);
+            const int t0 = (len - t > 0) ? (int)(r[1] % (uint32_t)(len - t)) : 0;
+            const int tend = (t > 0) ? t0 + (int)(r[2] % (uint32_t)t) : t0;
+            const int f = (int)(r[3] % (uint32_t)Fmask);
+            const int f0 = (D - f > 0) ? (int)(r2[0] % (uint32_t)(D - f)) : 0;
+            const int fend = (f > 0) ? f0 + (int)(r2[1] % (uint32_t)f) : f0;
+            dr[0] = t; dr[1] = t0; dr[2] = tend; dr[3] = f; dr[4] = f0; dr[5] = fend;
+        }
+        for (int i = 0; i < 6; ++i) { s_draw[i] = dr[i]; if (draws_out) draws_out[b * 6 + i] = dr[i]; }
+    }
+    __syncthreads();
+    const int t0 = s_draw[1], tend = (s_draw[0] > 0) ? s_draw[2] : s_draw[1];
+    const int f0 = s_draw[4], fend = (s_draw[3] > 0) ? s_draw[5] : s_draw[4];
+    if (len <= 0) return;
+    // sums over the valid region and over the rows of the time mask
+    double sum = 0.0, srow = 0.0;
+    const long n = (long)len * D;
+    for (long i = tid; i < n; i += 1024) {
+        const float v = xb[i];
+        sum += v;
+        const int t = (int)(i / D);
+        if (t >= t0 && t < tend) srow += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); srow += __shfl_xor(srow, o); }
+    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < 16; ++i) tot += s_red[i];
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = srow;
+    __syncthreads();
+    double rowtot = 0.0;
+    for (int i = 0; i < 16; ++i) rowtot += s_red[i];
+    const float mean1 = (float)(tot / (double)n);
+    const double nrow = (double)max(tend - t0, 0) * D;
+    const float mean2 = (float)((tot - rowtot + (double)mean1 * nrow) / (double)n);   // mean after the time mask
+    for (long i = tid; i < n; i += 1024) {
+        const int t = (int)(i / D), f = (int)(i % D);
+        if (f >= f0 && f < fend) xb[i] = mean2;
+        else if (t >= t0 && t < tend) xb[i] = mean1;
+    }
+}
+
+inline int grid_for(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+}  // namespace
+
+extern "C" size_t asr_fbank_workspace_bytes(int B, int T, int win, int n_fft) {
+    const size_t rows = (size_t)B * T, nb = n_fft / 2 + 1;
+    return (rows * win + rows * 2 * nb + rows * nb) * sizeof(float) + 1024;
+}
+
+extern "C" int asr_fbank(const float* wav, const int64_t* wav_len, float* out, const float* dft_table, const float* mel_fb,
+                         const float* window, int B, int N, int T, int win, int hop, int n_fft, int nmel,
+                         float preemph, float ref_db, float min_db,
+                         void* workspace, size_t workspace_bytes, asr_stream_t stream) {
+    ASR_REQUIRE(wav && wav_len && out && dft_table && mel_fb && window && workspace, ASR_E_ARG, "asr_fbank: null pointer");
+    ASR_REQUIRE(B > 0 && N > 0 && T > 0 && win > 0 && hop > 0 && n_fft >= win && nmel > 0, ASR_E_ARG, "asr_fbank: bad dims");
+    ASR_REQUIRE(workspace_bytes >= asr_fbank_workspace_bytes(B, T, win, n_fft), ASR_E_ARG, "asr_fbank: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)B * T;
+    const int nb = n_fft / 2 + 1;
+    float* frames = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* spec = frames + rows * win;
+    float* mag = spec + rows * 2 * nb;
+    hipLaunchKernelGGL(frame_kernel, dim3(grid_for(rows * win)), dim3(256), 0, st, wav, wav_len, frames, window, B, N, T, win, hop, n_fft, preemph);
+    // spec (rows, 2*nb) = frames (rows, win) x table^T, table (2*nb, win): exact fp32 MFMA
+    int rc = asr_gemm(frames, dft_table, spec, nullptr, (int)rows, 2 * nb, win, win, win, 2 * nb, 1, 1, ASR_ACT_NONE, 0, 1, 1, 0, 0, 0, 0, 0,
+                      ASR_F32, stream);
+    if (rc != ASR_OK) return rc;
+    hipLaunchKernelGGL(magnitude_kernel, dim3(grid_for(rows * nb)), dim3(256), 0, st, spec, mag, rows, nb);
+    rc = asr_gemm(mag, mel_fb, out, nullptr, (int)rows, nmel, nb, nb, nb, nmel, 1, 1, ASR_ACT_NONE, 0, 1, 1, 0, 0, 0, 0, 0, ASR_F32, stream);
+    if (rc != ASR_OK) return rc;
+    hipLaunchKernelGGL(logmel_kernel, dim3(grid_for(rows * nmel)), dim3(256), 0, st, out, wav_len, rows, T, nmel, hop, ref_db, min_db);
+    ASR_LAUNCH_CHECK("asr_fbank");
+    return ASR_OK;
+}
+
+extern "C" int asr_delta_stack(const float* x, const int64_t* lens, float* out, const float* filters,
+                               int B, int T, int F, int channels, int taps, asr_stream_t stream) {
+    ASR_REQUIRE(x && lens && out && filters && B > 0 && T > 0 && F > 0 && channels > 0 && taps > 0 && (taps & 1), ASR_E_ARG,
+                "asr_delta_stack: bad args");
+    hipLaunchKernelGGL(delta_stack_kernel, dim3(grid_for((long)B * T * channels * F)), dim3(256), 0, (hipStream_t)stream, x, lens, out,
+                       filters, B, T, F, channels, taps);
+    ASR_LAUNCH_CHECK("asr_delta_stack");
+    return ASR_OK;
+}
+
+extern "C" int asr_specaug(float* x, const int64_t* lens, const int* draws_in, int* draws_out, int B, int T, int D,
+                           int time_width, int freq_width, uint64_t seed, asr_stream_t stream) {
+    ASR_REQUIRE(x && lens && B > 0 && T > 0 && D > 0 && time_width > 0 && freq_width > 0, ASR_E_ARG, "asr_specaug: bad args");
+    hipLaunchKernelGGL(specaug_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, lens, draws_in, draws_out, B, T, D,
+                       time_width, freq_width, seed);
+    ASR_LAUNCH_CHECK("asr_specaug");
+    return ASR_OK;
+}

@@ -1,0 +1,180 @@
+"""GPU acoustic front-end with the reference's module names (src/audio.py): ExtractAudioFeature (fbank),
+Delta, Postprocess, Augment (SpecAugment), create_transform.  Unlike the reference — one utterance at a
+time on CPU DataLoader workers — these modules take a zero-padded BATCH on the device plus lengths and run
+the HIP kernels of csrc/frontend.hip.  Only constant tables (window, DFT basis, mel filterbank, delta
+filters) are built on the host."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from src import hipabi as H
+
+SAMPLE_RATE = 16000
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mel = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mel)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def create_mel_filterbank(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
+    """Slaney-style, area-normalised triangular filterbank over the 1 + n_fft//2 FFT bins — the table the
+    reference builds at src/audio.py:149-156, 491-605 (pinned against its output in tests/golden)."""
+    fmax = float(sr) / 2 if fmax is None else fmax
+    nb = 1 + n_fft // 2
+    fftfreqs = np.linspace(0, float(sr) / 2, nb)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, nb))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def delta_filters(order, window_size):
+    """Delta._create_filters (src/audio.py:73-93): rows = [static, delta, (delta-delta)], zero-padded to equal length."""
+    scales = [[1.0]]
+    for i in range(1, order + 1):
+        prev_off = (len(scales[i - 1]) - 1) // 2
+        cur_off = prev_off + window_size
+        cur = [0.0] * (len(scales[i - 1]) + 2 * window_size)
+        norm = 0.0
+        for j in range(-window_size, window_size + 1):
+            norm += j * j
+            for k in range(-prev_off, prev_off + 1):
+                cur[j + k + cur_off] += j * scales[i - 1][k + prev_off]
+        scales.append([x / norm for x in cur])
+    n = len(scales[-1])
+    out = np.zeros((order + 1, n), dtype=np.float32)
+    for i, sc in enumerate(scales):
+        pad = (n - len(sc)) // 2
+        out[i, pad:pad + len(sc)] = sc
+    return out
+
+
+class ExtractAudioFeature(nn.Module):
+    """wav (B,N) fp32 on the device + wav_len (B) -> (B,T,num_mel_bins) in [0,1], frame lengths."""
+
+    def __init__(self, mode='fbank', num_mel_bins=80, frame_length=25, frame_shift=10, ref_level_db=20, min_level_db=-100,
+                 preemphasis_coeff=0.97, sample_rate=SAMPLE_RATE):
+        super().__init__()
+        assert mode == 'fbank'
+        self.n_fft = 1025
+        self.hop = int(frame_shift / 1000 * sample_rate)
+        self.win = int(frame_length / 1000 * sample_rate)
+        self.nmel, self.ref_db, self.min_db, self.preemph = num_mel_bins, float(ref_level_db), float(min_level_db), float(preemphasis_coeff)
+        nb = self.n_fft // 2 + 1
+        m = np.arange(self.win, dtype=np.float64) + (self.n_fft - self.win) // 2
+        ang = 2.0 * np.pi * np.arange(nb, dtype=np.float64)[:, None] * m[None, :] / self.n_fft
+        table = np.concatenate([np.cos(ang), -np.sin(ang)], 0).astype(np.float32)
+        self.register_buffer('dft_table', torch.from_numpy(table), persistent=False)
+        self.register_buffer('mel_fb', torch.from_numpy(create_mel_filterbank(sample_rate, self.n_fft, num_mel_bins)), persistent=False)
+        self.register_buffer('window', torch.hann_window(self.win, periodic=True), persistent=False)
+
+    def forward(self, wav, wav_len):
+        wav = wav.contiguous().float()
+        wav_len = wav_len.to(wav.device, torch.int64).contiguous()
+        B, N = wav.shape
+        T = 1 + (N - 1) // self.hop      # torch.stft(center=True) with odd n_fft
+        out = torch.empty((B, T, self.nmel), dtype=torch.float32, device=wav.device)
+        nbytes = H.lib().asr_fbank_workspace_bytes(B, T, self.win, self.n_fft)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=wav.device)
+        H.call('asr_fbank', H.ptr(wav), H.ptr(wav_len), H.ptr(out), H.ptr(self.dft_table), H.ptr(self.mel_fb), H.ptr(self.window),
+               B, N, T, self.win, self.hop, self.n_fft, self.nmel, self.preemph, self.ref_db, self.min_db, H.ptr(ws), nbytes,
+               H.stream_ptr())
+        return out, 1 + (wav_len - 1) // self.hop
+
+
+class Delta(nn.Module):
+    """(B,T,F) + lens -> (B,T,(order+1)*F), channel-major like Postprocess emits it."""
+
+    def __init__(self, order=2, window_size=2):
+        super().__init__()
+        self.order = order
+        self.register_buffer('filters', torch.from_numpy(delta_filters(order, window_size)), persistent=False)
+
+    def forward(self, x, lens):
+        x = x.contiguous()
+        B, T, F = x.shape
+        C, taps = self.filters.shape
+        out = torch.empty((B, T, C * F), dtype=torch.float32, device=x.device)
+        lens = lens.to(x.device, torch.int64).contiguous()
+        H.call('asr_delta_stack', H.ptr(x), H.ptr(lens), H.ptr(out), H.ptr(self.filters), B, T, F, C, taps, H.stream_ptr())
+        return out, lens
+
+
+class Postprocess(nn.Module):
+    """Kept for name compatibility: the HIP front-end already emits the (T, C*F) layout."""
+
+    def forward(self, x, lens):
+        return x, lens
+
+
+class Augment(nn.Module):
+    """SpecAugment (one time mask <= T, one frequency mask <= F, mean fill), in place on the padded batch."""
+
+    def __init__(self, T=40, num_masks=1, replace_with_zero=False, F=27, seed=0):
+        super().__init__()
+        assert num_masks == 1 and not replace_with_zero
+        self.T, self.F, self.seed, self.calls = T, F, seed, 0
+
+    def forward(self, x, lens, draws=None):
+        B, T, D = x.shape
+        lens = lens.to(x.device, torch.int64).contiguous()
+        d_in = None
+        if draws is not None:
+            d_in = draws.to(x.device, torch.int32).contiguous()
+        self.calls += 1
+        H.call('asr_specaug', H.ptr(x), H.ptr(lens), H.ptr(d_in), None, B, T, D, self.T, self.F,
+               (self.seed * 1000003 + self.calls) & 0xFFFFFFFFFFFF, H.stream_ptr())
+        return x, lens
+
+
+class FrontEnd(nn.Module):
+    def __init__(self, stages):
+        super().__init__()
+        self.stages = nn.ModuleList(stages)
+
+    def forward(self, x, lens):
+        for s in self.stages:
+            x, lens = s(x, lens)
+        return x, lens
+
+
+def create_transform(audio_config, mode='train'):
+    """Same keys as the reference's create_transform (src/audio.py:453-486); returns (module, feature dim)."""
+    cfg = dict(audio_config)
+    delta_order = cfg.pop('delta_order', 0)
+    delta_window = cfg.pop('delta_window_size', 2)
+    if cfg.pop('apply_cmvn', False):
+        raise NotImplementedError('CMVN is not part of the HIP front-end')
+    feat_type, feat_dim = cfg.pop('feat_type'), cfg.pop('feat_dim')
+    augment = cfg.pop('augment', False)
+    cfg.pop('time_aug', False)
+    stages = [ExtractAudioFeature(mode=feat_type, num_mel_bins=feat_dim, sample_rate=SAMPLE_RATE, **cfg)]
+    if delta_order >= 1:
+        stages.append(Delta(delta_order, delta_window))
+    stages.append(Postprocess())
+    if augment and mode == 'train':
+        stages.append(Augment())
+    return FrontEnd(stages), feat_dim * (delta_order + 1)

@@ -54,6 +54,9 @@ SIGNATURES = {
     'asr_xent': [_vp, _vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     'asr_att_decoder_fwd': [_P(DecDims), _P(DecWeights), _vp, _vp, _vp, _i, _P(DecState), _i, _vp],
     'asr_att_decoder_bwd': [_P(DecDims), _P(DecWeights), _P(DecWeights), _vp, _vp, _P(DecState), _vp, _vp, _vp, _sz, _i, _vp],
+    'asr_fbank': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _sz, _vp],
+    'asr_delta_stack': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'asr_specaug': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u64, _vp],
     'asr_sumsq': [_vp, _l, _vp, _vp],
     'asr_scale': [_vp, _l, _f, _vp],
     'asr_adadelta_step': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp],
@@ -65,6 +68,7 @@ _RESTYPES = {
     'asr_lstm_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_lstm_set_persistent': (ctypes.c_int, [_i]),
     'asr_ctc_loss_workspace_bytes': (_sz, [_i, _i, _i]),
+    'asr_fbank_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'asr_att_decoder_bwd_workspace_bytes': (_sz, [_P(DecDims)]),
 }
 

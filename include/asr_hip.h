@@ -207,6 +207,28 @@ int asr_adadelta_step(float* param, const float* grad, float* square_avg, float*
                       float lr, float rho, float eps, float weight_decay, float clip,
                       const double* normsq, float grad_mul, asr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Acoustic front-end, batched on the GPU (the reference runs it per utterance in DataLoader workers).
+ *   asr_fbank: ExtractAudioFeature.forward (src/audio.py:158-171, 231-244).  wav (B,N) fp32 zero-padded,
+ *     wav_len (B) samples; out (B,T,nmel), T >= 1 + (max(wav_len)-1)/hop, frames beyond an utterance are 0.
+ *     dft_table (2*(n_fft/2+1), win): rows f = cos, rows nb+f = -sin of 2*pi*f*(m + (n_fft-win)/2)/n_fft;
+ *     mel_fb (nmel, n_fft/2+1); window (win).  Tables are built by the host (src/audio.py).
+ *   asr_delta_stack: Delta + Postprocess (src/audio.py:59-93, 108-121).  x (B,T,F), lens (B) frames,
+ *     filters (channels, taps) as Delta._create_filters builds them; out (B,T,channels*F) channel-major.
+ *   asr_specaug: Augment (src/audio.py:364-406), in place on x (B,T,D) using lens.  draws_in (B,6) int32 =
+ *     {t, t0, tend, f, f0, fend} in the reference's draw order, or NULL to draw on the device
+ *     (Philox, seed); draws_out (B,6) optional.
+ */
+size_t asr_fbank_workspace_bytes(int B, int T, int win, int n_fft);
+int asr_fbank(const float* wav, const int64_t* wav_len, float* out, const float* dft_table, const float* mel_fb,
+              const float* window, int B, int N, int T, int win, int hop, int n_fft, int nmel,
+              float preemph, float ref_db, float min_db,
+              void* workspace, size_t workspace_bytes, asr_stream_t stream);
+int asr_delta_stack(const float* x, const int64_t* lens, float* out, const float* filters,
+                    int B, int T, int F, int channels, int taps, asr_stream_t stream);
+int asr_specaug(float* x, const int64_t* lens, const int* draws_in, int* draws_out, int B, int T, int D,
+                int time_width, int freq_width, uint64_t seed, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

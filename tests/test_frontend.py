@@ -1,0 +1,98 @@
+"""Front-end parity.  CPU: oracle + host tables vs the reference fixtures (g5).  GPU: HIP kernels vs the same
+fixtures (delta/postprocess/SpecAugment with recorded draws: exact fp32) and vs the torch.stft oracle (fbank)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend_oracle as FO
+
+
+@pytest.fixture(scope='module')
+def g5(golden_dir):
+    return np.load(os.path.join(golden_dir, 'g5_frontend.npz'))
+
+
+def test_oracle_and_tables_match_reference(g5):
+    from src.audio import create_mel_filterbank, delta_filters
+    np.testing.assert_allclose(create_mel_filterbank(16000, 1025, 80), g5['melfb'], atol=1e-7)
+    for order in (1, 2):
+        filt = delta_filters(order, 2)
+        np.testing.assert_allclose(filt, g5['filters%d' % order].reshape(order + 1, -1), atol=1e-7)
+        d = FO.delta(g5['mel'], filt)
+        np.testing.assert_allclose(d.numpy(), g5['delta%d' % order], atol=1e-6)
+        np.testing.assert_allclose(FO.postprocess(d).numpy(), g5['post%d' % order], atol=1e-6)
+    for i, dr in enumerate(g5['aug_draws']):
+        np.testing.assert_allclose(FO.augment(g5['aug_in'], dr).numpy(), g5['aug_out%d' % i], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_delta_stack_matches_reference(g5):
+    from src.audio import Delta
+    mel = torch.from_numpy(g5['mel'])[0].t().contiguous()            # (T,F)
+    T, Fd = mel.shape
+    for order in (1, 2):
+        # batch of two: the fixture utterance and a shorter copy padded with garbage that must not leak in
+        x = torch.zeros(2, T + 5, Fd)
+        x[0, :T] = mel
+        x[0, T:] = 7.0
+        x[1, :T - 9] = mel[:T - 9]
+        x[1, T - 9:] = -3.0
+        out, _ = Delta(order, 2).cuda()(x.cuda(), torch.tensor([T, T - 9]).cuda())
+        out = out.cpu()
+        np.testing.assert_allclose(out[0, :T].numpy(), g5['post%d' % order], atol=1e-6)
+        assert float(out[0, T:].abs().max()) == 0.0
+        ref1 = FO.postprocess(FO.delta(g5['mel'][:, :, :T - 9], g5['filters%d' % order].reshape(order + 1, -1)))
+        np.testing.assert_allclose(out[1, :T - 9].numpy(), ref1.numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_specaugment_matches_reference(g5):
+    from src.audio import Augment
+    x0 = torch.from_numpy(g5['aug_in'])
+    T, D = x0.shape
+    draws = torch.from_numpy(g5['aug_draws']).int()
+    nb = draws.shape[0]
+    x = torch.zeros(nb, T + 11, D)
+    x[:, :T] = x0
+    x[:, T:] = 9.0          # padding must be ignored by the mean and left untouched
+    aug = Augment().cuda()
+    out, _ = aug(x.cuda(), torch.full((nb,), T).cuda(), draws=draws)
+    out = out.cpu()
+    for i in range(nb):
+        np.testing.assert_allclose(out[i, :T].numpy(), g5['aug_out%d' % i], atol=2e-6)
+        assert float((out[i, T:] - 9.0).abs().max()) == 0.0
+    # device-side draws: masks must be legal (inside the utterance, widths below T / F) and mean-filled
+    y = torch.rand(4, 300, 160)
+    lens = torch.tensor([300, 250, 200, 41])
+    yd = y.clone().cuda()
+    aug(yd, lens.cuda())
+    changed = (yd.cpu() != y)
+    for b in range(4):
+        assert not changed[b, lens[b]:].any()
+        rows = changed[b].all(dim=1).nonzero().flatten()
+        cols = changed[b, :lens[b]].all(dim=0).nonzero().flatten()
+        assert len(rows) < 40 and len(cols) < 27
+
+
+@pytest.mark.gpu
+def test_hip_fbank_matches_stft_oracle():
+    from src.audio import ExtractAudioFeature, create_mel_filterbank
+    g = torch.Generator().manual_seed(0)
+    lens = torch.tensor([16000, 12345, 801])
+    wav = torch.zeros(3, 16000)
+    for b in range(3):
+        t = torch.arange(int(lens[b])) / 16000.0
+        wav[b, :lens[b]] = 0.3 * torch.sin(2 * np.pi * (200 + 900 * b) * t) + 0.05 * torch.randn(int(lens[b]), generator=g)
+    fe = ExtractAudioFeature().cuda()
+    out, flen = fe(wav.cuda(), lens.cuda())
+    out = out.cpu()
+    fb = create_mel_filterbank(16000, 1025, 80)
+    for b in range(3):
+        ref = FO.fbank(wav[b:b + 1, :lens[b]], fb)[0].t()           # (T_b, 80)
+        Tb = ref.shape[0]
+        assert int(flen[b]) == Tb
+        assert float((out[b, :Tb] - ref).abs().max()) < 2e-4         # fp32 DFT-as-contraction vs FFT
+        if Tb < out.shape[1]:
+            assert float(out[b, Tb:].abs().max()) == 0.0

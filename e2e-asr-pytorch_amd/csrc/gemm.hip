@@ -24,7 +24,18 @@ struct GemmP {
     int act, accum;
     int seqT, bshift;
     int vecA, vecB;
+    // implicit 3x3 convolution over a channel-last image (rows = (b,t,f), cT x cF pixels, cC channels):
+    // the conv operand's reduction/column index k = tap*cC + ci addresses pixel (t+dt, f+df), zero outside.
+    int convA, convB, cT, cF, cC;
 };
+
+// source row offset and validity of tap (dt,df) for pixel row m
+__device__ __forceinline__ bool conv_tap(int m, int tap, int cT, int cF, long& src_row) {
+    const int f = m % cF, t = (m / cF) % cT;
+    const int dt = tap / 3 - 1, df = tap % 3 - 1;
+    src_row = (long)m + (long)dt * cF + df;
+    return (unsigned)(t + dt) < (unsigned)cT && (unsigned)(f + df) < (unsigned)cF;
+}
 
 // One operand tile in LDS.  KC=true : image [row][k] (row = i or j), k contiguous.
 //                           KC=false: image [k][row], row contiguous (same as memory).
@@ -40,12 +51,36 @@ template <> struct TileLayout<false, false> { static constexpr int LD = 128 + 4;
 // rmask(k) gives validity of reduction index k (used for the shifted/masked wgrad operand).
 template <bool KC>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ base, long ld, int row0, int nrows,
-                                           int k0, int kend, int vec, int seqT, int shift, float4 (&r)[4]) {
+                                           int k0, int kend, int vec, int seqT, int shift, float4 (&r)[4],
+                                           int conv = 0, int cT = 0, int cF = 0, int cC = 0) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KC) {
+        if (conv) {
+            // element (pixel row m, k = tap*cC + ci) = image[(m + dt*cF + df)*cC + ci]
+            int m, k;
+            if (KC) { m = row0 + (tid >> 3) + 32 * q; k = k0 + (tid & 7) * 4; }
+            else    { m = k0 + (tid >> 5) + 8 * q;   k = row0 + (tid & 31) * 4; }
+            const int mend = KC ? nrows : kend, kk_end = KC ? kend : nrows;
+            if (m < mend && k < kk_end) {
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((cC & 3) == 0 && k + 3 < kk_end) {
+                    long src;
+                    if (conv_tap(m, k / cC, cT, cF, src)) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(base + src * cC + (k % cC));
+                        e[0] = t4.x; e[1] = t4.y; e[2] = t4.z; e[3] = t4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        long src;
+                        if (k + i < kk_end && conv_tap(m, (k + i) / cC, cT, cF, src)) e[i] = base[src * cC + ((k + i) % cC)];
+                    }
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        } else if (KC) {
             int row = row0 + (tid >> 3) + 32 * q;
             int k = k0 + (tid & 7) * 4;
             if (row < nrows) {
@@ -170,16 +205,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 ra[4], rb[4];
-    fetch_tile<AKC>(A, p.lda, i0, p.M, kt0 * BK, p.K, p.vecA, 0, 0, ra);
-    fetch_tile<BKC>(B, p.ldb, j0, p.N, kt0 * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb);
+    fetch_tile<AKC>(A, p.lda, i0, p.M, kt0 * BK, p.K, p.vecA, 0, 0, ra, p.convA, p.cT, p.cF, p.cC);
+    fetch_tile<BKC>(B, p.ldb, j0, p.N, kt0 * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb, p.convB, p.cT, p.cF, p.cC);
 
     for (int kt = kt0; kt < kt1; ++kt) {
         stash_tile<BF16, AKC>(As, ra);
         stash_tile<BF16, BKC>(Bs, rb);
         __syncthreads();
         if (kt + 1 < kt1) {
-            fetch_tile<AKC>(A, p.lda, i0, p.M, (kt + 1) * BK, p.K, p.vecA, 0, 0, ra);
-            fetch_tile<BKC>(B, p.ldb, j0, p.N, (kt + 1) * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb);
+            fetch_tile<AKC>(A, p.lda, i0, p.M, (kt + 1) * BK, p.K, p.vecA, 0, 0, ra, p.convA, p.cT, p.cF, p.cC);
+            fetch_tile<BKC>(B, p.ldb, j0, p.N, (kt + 1) * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb, p.convB, p.cT, p.cF, p.cC);
         }
         if (BF16) {
             bf16x8 fa[4], fb[4];
@@ -268,9 +303,40 @@ extern "C" int asr_gemm(const float* A, const float* B, float* C, const float* b
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sA = sA; p.sB = sB; p.sC = sC; p.batch = batch; p.splits = splits;
     p.act = act; p.accum = accum; p.seqT = seqT; p.bshift = bshift;
+    p.convA = p.convB = p.cT = p.cF = p.cC = 0;
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda % 4) == 0 && (sA % 4) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B & 15) == 0 && (ldb % 4) == 0 && (sB % 4) == 0) ? 1 : 0;
     // the shifted operand reads rows at an offset; stays 16B aligned because ldb%4==0
     hipStream_t st = (hipStream_t)stream;
     return prec == ASR_BF16 ? launch_gemm<true>(p, a_kc, b_kc, st) : launch_gemm<false>(p, a_kc, b_kc, st);
+}
+
+// 3x3 / stride 1 / pad 1 convolution over channel-last images as an implicit GEMM.
+//   mode 0 (forward / dgrad): out[(b,t,f), n] (+)= act( sum_{tap,ci} img[(b,t+dt,f+df), ci] * w[n][tap*C + ci] + bias[n] )
+//   mode 1 (wgrad)          : dw[n][tap*C + ci] += sum_{(b,t,f)} dout[(b,t,f), n] * img[(b,t+dt,f+df), ci]
+extern "C" int asr_conv3x3(const float* img, const float* w_or_dout, float* out, const float* bias,
+                           int B, int T, int F, int C, int N, int mode, int act, int accum, int prec, asr_stream_t stream) {
+    ASR_REQUIRE(img && w_or_dout && out, ASR_E_ARG, "asr_conv3x3: null pointer");
+    ASR_REQUIRE(B > 0 && T > 0 && F > 0 && C > 0 && N > 0, ASR_E_ARG, "asr_conv3x3: bad dims");
+    ASR_REQUIRE((long)B * T * F < (1L << 31), ASR_E_UNSUPPORTED, "asr_conv3x3: more than 2^31 pixels");
+    GemmP p;
+    const int rows = B * T * F, K9 = 9 * C;
+    p.bias = bias; p.act = act; p.accum = accum; p.seqT = 0; p.bshift = 0; p.batch = 1; p.sA = p.sB = p.sC = 0;
+    p.cT = T; p.cF = F; p.cC = C;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) {
+        p.A = img; p.B = w_or_dout; p.C = out; p.M = rows; p.N = N; p.K = K9; p.lda = C; p.ldb = K9; p.ldc = N;
+        p.convA = 1; p.convB = 0; p.splits = 1;
+        p.vecA = (((uintptr_t)img & 15) == 0) ? 1 : 0;
+        p.vecB = (((uintptr_t)w_or_dout & 15) == 0 && (K9 % 4) == 0) ? 1 : 0;
+        return prec == ASR_BF16 ? launch_gemm<true>(p, 1, 1, st) : launch_gemm<false>(p, 1, 1, st);
+    }
+    // wgrad: C[i = n, j = (tap,ci)] += sum_r dout[r, i] * conv(img)[r, j]
+    ASR_REQUIRE(accum == 1 && act == ASR_ACT_NONE && bias == nullptr, ASR_E_ARG, "asr_conv3x3: wgrad accumulates without epilogue");
+    p.A = w_or_dout; p.B = img; p.C = out; p.M = N; p.N = K9; p.K = rows; p.lda = N; p.ldb = C; p.ldc = K9;
+    p.convA = 0; p.convB = 1;
+    p.splits = rows >= 65536 ? 32 : (rows >= 4096 ? 8 : 1);
+    p.vecA = (((uintptr_t)w_or_dout & 15) == 0 && (N % 4) == 0) ? 1 : 0;
+    p.vecB = (((uintptr_t)img & 15) == 0) ? 1 : 0;
+    return prec == ASR_BF16 ? launch_gemm<true>(p, 0, 0, st) : launch_gemm<false>(p, 0, 0, st);
 }

@@ -208,6 +208,9 @@ class ASR(nn.Module):
         layers = [m for m in self.encoder.layers if isinstance(m, RNNLayer)]
         for i, m in enumerate(layers[::-1]):
             m.dp, m.bucket = dp, len(rest) + i
+        for m in self.encoder.layers:
+            if not isinstance(m, RNNLayer) and hasattr(m, 'bucket') and front:
+                m.dp, m.bucket = dp, len(buckets) - 1
         self._dp, self._n_rest = dp, len(rest)
         return dp
 

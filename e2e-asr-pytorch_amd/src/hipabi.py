@@ -57,6 +57,13 @@ SIGNATURES = {
     'asr_fbank': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _sz, _vp],
     'asr_delta_stack': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'asr_specaug': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u64, _vp],
+    'asr_conv3x3': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'asr_conv_weight_permute': [_vp, _vp, _i, _i, _i, _vp],
+    'asr_maxpool2x2_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'asr_maxpool2x2_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'asr_ln_freq_fwd': [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp],
+    'asr_ln_freq_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
+    'asr_permute_last2': [_vp, _vp, _l, _i, _i, _vp],
     'asr_sumsq': [_vp, _l, _vp, _vp],
     'asr_scale': [_vp, _l, _f, _vp],
     'asr_adadelta_step': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp],

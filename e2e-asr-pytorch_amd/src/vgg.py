@@ -1,0 +1,166 @@
+"""VGG front-ends of the encoder on the HIP path, with the reference's module/parameter names
+(VGGExtractor src/module.py:659-716, VGGExtractor_LN src/module.py:582-657; `extractor.<i>.weight` keys).
+
+Activations are channel-last images (B,T,F,C); every convolution is asr_conv3x3 (implicit GEMM on MFMA:
+forward, input gradient with the flipped weight copy, weight gradient), pooling and LayerNorm-over-frequency
+are the HBM-bound kernels of csrc/vgg.hip."""
+import torch
+import torch.nn as nn
+
+from src import hipabi as H
+
+FBANK_SIZE = 40
+
+
+class CNNLayerNorm(nn.Module):
+    def __init__(self, n_feats):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(n_feats)
+
+
+def _e(shape, dev, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class _VGGFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, feature, mod, prec):
+        st = H.stream_ptr()
+        dev = feature.device
+        if feature.shape[1] % 4 != 0:
+            feature = feature[:, :-(feature.shape[1] % 4), :]
+        feature = feature.contiguous()
+        B, T, _ = feature.shape
+        Cin, F = mod.in_channel, mod.freq_dim
+        x = _e((B, T, F, Cin), dev)
+        H.call('asr_permute_last2', H.ptr(feature), H.ptr(x), B * T, Cin, F, st)      # (.., C, F) -> (.., F, C)
+        saved = {'x': [], 'pre': [], 'stats': [], 'idx': [], 'dims': []}
+        cur, t, f = x, T, F
+        for li, (conv, ln) in enumerate(mod.conv_layers()):
+            Co, Ci = conv.weight.shape[0], conv.weight.shape[1]
+            wf = _e((Co, 9 * Ci), dev)
+            H.call('asr_conv_weight_permute', H.ptr(conv.weight), H.ptr(wf), Co, Ci, 0, st)
+            out = _e((B, t, f, Co), dev)
+            saved['x'].append(cur)
+            saved['dims'].append((t, f, Ci, Co))
+            if ln is None:
+                H.call('asr_conv3x3', H.ptr(cur), H.ptr(wf), H.ptr(out), H.ptr(conv.bias), B, t, f, Ci, Co, 0, H.ACT_RELU, 0, prec, st)
+                saved['pre'].append(None); saved['stats'].append(None)
+                act = out
+            else:
+                H.call('asr_conv3x3', H.ptr(cur), H.ptr(wf), H.ptr(out), H.ptr(conv.bias), B, t, f, Ci, Co, 0, H.ACT_NONE, 0, prec, st)
+                act = _e((B, t, f, Co), dev)
+                stats = _e((B * t * Co, 2), dev)
+                H.call('asr_ln_freq_fwd', H.ptr(out), H.ptr(ln.weight), H.ptr(ln.bias), H.ptr(act), H.ptr(stats), B * t, f, Co, 1e-5, 1, st)
+                saved['pre'].append(out); saved['stats'].append(stats)
+            if li in (1, 3):
+                t2, f2 = ((t + 1) // 2, (f + 1) // 2) if mod.ceil_mode else (t // 2, f // 2)
+                pooled = _e((B, t2, f2, Co), dev)
+                idx = _e((B, t2, f2, Co), dev, torch.uint8)
+                H.call('asr_maxpool2x2_fwd', H.ptr(act), H.ptr(pooled), H.ptr(idx), B, t, f, Co, t2, f2, st)
+                saved['idx'].append((idx, act, t, f, t2, f2))
+                cur, t, f = pooled, t2, f2
+            else:
+                saved['idx'].append(None)
+                cur = act
+            saved.setdefault('act', []).append(act)
+        Co = cur.shape[-1]
+        out = _e((B, t, Co * f), dev)
+        H.call('asr_permute_last2', H.ptr(cur), H.ptr(out), B * t, f, Co, st)           # (.., F, C) -> (.., C, F)
+        ctx.mod, ctx.prec, ctx.saved, ctx.B = mod, prec, saved, B
+        ctx.final = (t, f, Co)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, prec, sv, B = ctx.mod, ctx.prec, ctx.saved, ctx.B
+        st = H.stream_ptr()
+        dev = dout.device
+        t, f, Co = ctx.final
+        dout = dout.contiguous()
+        g = _e((B, t, f, Co), dev)
+        H.call('asr_permute_last2', H.ptr(dout), H.ptr(g), B * t, Co, f, st)            # (.., C, F) -> (.., F, C)
+        layers = list(mod.conv_layers())
+        for li in range(len(layers) - 1, -1, -1):
+            conv, ln = layers[li]
+            t_l, f_l, Ci, Co = sv['dims'][li]
+            if sv['idx'][li] is not None:
+                idx, act, tt, ff, t2, f2 = sv['idx'][li]
+                gp = _e((B, tt, ff, Co), dev)
+                H.call('asr_maxpool2x2_bwd', H.ptr(g), H.ptr(idx), H.ptr(gp), B, tt, ff, Co, t2, f2, st)
+                g = gp
+            act = sv['act'][li]
+            dpre = _e((B, t_l, f_l, Co), dev)
+            if ln is None:
+                H.call('asr_act_bwd', H.ptr(g), H.ptr(act), H.ptr(dpre), g.numel(), H.ACT_RELU, st)
+            else:
+                H.call('asr_ln_freq_bwd', H.ptr(g), H.ptr(sv['pre'][li]), H.ptr(ln.weight), H.ptr(ln.bias), H.ptr(sv['stats'][li]),
+                       H.ptr(dpre), H.ptr(ln.weight.grad), H.ptr(ln.bias.grad), B * t_l, f_l, Co, 1, st)
+            xin = sv['x'][li]
+            dwf = torch.zeros((Co, 9 * Ci), dtype=torch.float32, device=dev)
+            H.call('asr_conv3x3', H.ptr(xin), H.ptr(dpre), H.ptr(dwf), None, B, t_l, f_l, Ci, Co, 1, H.ACT_NONE, 1, prec, st)
+            H.call('asr_conv_weight_permute', H.ptr(dwf), H.ptr(conv.weight.grad), Co, Ci, 2, st)
+            H.call('asr_colsum', H.ptr(dpre), Co, B * t_l * f_l, Co, H.ptr(conv.bias.grad), st)
+            if li > 0:
+                wd = _e((Ci, 9 * Co), dev)
+                H.call('asr_conv_weight_permute', H.ptr(conv.weight), H.ptr(wd), Co, Ci, 1, st)
+                gin = _e((B, t_l, f_l, Ci), dev)
+                H.call('asr_conv3x3', H.ptr(dpre), H.ptr(wd), H.ptr(gin), None, B, t_l, f_l, Co, Ci, 0, H.ACT_NONE, 0, prec, st)
+                g = gin
+        if mod.dp is not None:
+            mod.dp.bucket_ready(mod.bucket)
+        ctx.saved = None
+        return None, None, None, None
+
+
+class _VGGBase(nn.Module):
+    def check_dim(self, input_dim):
+        if input_dim % FBANK_SIZE != 0:
+            raise ValueError('HIP VGG front-end expects 40-bin fbank channels (input dim %d)' % input_dim)
+        return input_dim // FBANK_SIZE, FBANK_SIZE, (FBANK_SIZE // 4) * self.hide_dim
+
+    def forward(self, feature, feat_len, ctx=None):
+        out = _VGGFn.apply(ctx.anchor, feature, self, ctx.prec)
+        return out, feat_len // 4
+
+
+class VGGExtractor(_VGGBase):
+    ''' VGG extractor (reference src/module.py:659-716): 2x(conv3x3+ReLU) -> maxpool(ceil) -> 2x(conv3x3+ReLU) -> maxpool(ceil) '''
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.init_dim, self.hide_dim, self.ceil_mode = 128, 256, True
+        self.in_channel, self.freq_dim, self.out_dim = self.check_dim(input_dim)
+        self.dp, self.bucket = None, None
+        self.extractor = nn.Sequential(
+            nn.Conv2d(self.in_channel, self.init_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.Conv2d(self.init_dim, self.init_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2, ceil_mode=True),
+            nn.Conv2d(self.init_dim, self.hide_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.Conv2d(self.hide_dim, self.hide_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2, ceil_mode=True))
+
+    def conv_layers(self):
+        return [(self.extractor[i], None) for i in (0, 2, 5, 7)]
+
+
+class VGGExtractor_LN(_VGGBase):
+    ''' VGG + LayerNorm over frequency (reference src/module.py:582-657), floor-mode pooling '''
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.init_dim, self.hide_dim, self.ceil_mode = 64, 128, False
+        self.in_channel, self.freq_dim, self.out_dim = self.check_dim(input_dim)
+        self.upstream = False
+        self.dp, self.bucket = None, None
+        n = FBANK_SIZE
+        self.extractor = nn.Sequential(
+            nn.Conv2d(self.in_channel, self.init_dim, 3, stride=1, padding=1), CNNLayerNorm(n), nn.ReLU(),
+            nn.Conv2d(self.init_dim, self.init_dim, 3, stride=1, padding=1), CNNLayerNorm(n), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(self.init_dim, self.hide_dim, 3, stride=1, padding=1), CNNLayerNorm(n // 2), nn.ReLU(),
+            nn.Conv2d(self.hide_dim, self.hide_dim, 3, stride=1, padding=1), CNNLayerNorm(n // 2), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2))
+
+    def conv_layers(self):
+        return [(self.extractor[i], self.extractor[i + 1].layer_norm) for i in (0, 3, 7, 10)]

@@ -229,6 +229,29 @@ int asr_delta_stack(const float* x, const int64_t* lens, float* out, const float
 int asr_specaug(float* x, const int64_t* lens, const int* draws_in, int* draws_out, int B, int T, int D,
                 int time_width, int freq_width, uint64_t seed, asr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * VGG front-ends (VGGExtractor src/module.py:659-716, VGGExtractor_LN :582-657) on channel-last images
+ * (B,T,F,C).  asr_conv3x3 = nn.Conv2d(k=3, stride 1, pad 1) as an implicit GEMM on MFMA:
+ *   mode 0: out[(b,t,f), n] (+)= act( sum_{tap,ci} img[(b,t+dt,f+df), ci] * w[n][tap*C+ci] + bias[n] )
+ *           (forward with the (Co, 9*Ci) weight copy; input gradient with the flipped (Ci, 9*Co) copy)
+ *   mode 1: dw[n][tap*C+ci] += sum_pixels dout[pixel, n] * img[pixel shifted by tap, ci]   (w_or_dout = dout)
+ * asr_conv_weight_permute builds those copies from / folds the gradient back into the reference's
+ * (Co,Ci,3,3) tensors (modes 0,1,2).  asr_maxpool2x2_* = nn.MaxPool2d(2, stride 2[, ceil_mode]); idx keeps
+ * the arg-max (0..3).  asr_ln_freq_* = CNNLayerNorm (LayerNorm over F, affine per f) + optional ReLU;
+ * stats (rows*C, 2).  asr_permute_last2: out[r,b,a] = in[r,a,b] (channel-major <-> channel-last).
+ */
+int asr_conv3x3(const float* img, const float* w_or_dout, float* out, const float* bias,
+                int B, int T, int F, int C, int N, int mode, int act, int accum, int prec, asr_stream_t stream);
+int asr_conv_weight_permute(const float* src, float* dst, int Co, int Ci, int mode, asr_stream_t stream);
+int asr_maxpool2x2_fwd(const float* x, float* y, unsigned char* idx, int B, int T, int F, int C, int T2, int F2, asr_stream_t stream);
+int asr_maxpool2x2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int T, int F, int C, int T2, int F2,
+                       asr_stream_t stream);
+int asr_ln_freq_fwd(const float* x, const float* w, const float* b, float* y, float* stats, long rows, int F, int C,
+                    float eps, int relu, asr_stream_t stream);
+int asr_ln_freq_bwd(const float* dy, const float* x, const float* w, const float* b, const float* stats,
+                    float* dx, float* dw, float* db, long rows, int F, int C, int relu, asr_stream_t stream);
+int asr_permute_last2(const float* in, float* out, long rows, int A, int Bd, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

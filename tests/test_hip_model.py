@@ -172,6 +172,39 @@ def test_full_size_librispeech_config(golden_dir, prec):
     finish(report)
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('name', ['g3_small_vgg1', 'g3_small_vgg5'])
+def test_vgg_front_ends_vs_reference_fixtures(golden_dir, name, prec):
+    """VGGExtractor (vgg 1) and VGGExtractor_LN (vgg 5): outputs, losses, per-parameter gradient norms + heads."""
+    meta, z = load(golden_dir, name)
+    cfg, sd, model = build(meta, prec)
+    model.eval()
+    res = hip_step(model, torch.from_numpy(z['feat']), torch.from_numpy(z['feat_len']), torch.from_numpy(z['txt']), False)
+    assert np.array_equal(res['enc_len'].cpu().numpy(), z['enc_len'])
+    f32 = prec == 'fp32'
+    report = []
+    for key in ('ctc_loss', 'att_loss', 'total_loss'):
+        r = float(z[key])
+        err = abs(float(res[key].detach()) - r)
+        tol = (2e-5 if f32 else 2e-2) * max(1.0, abs(r))
+        report.append((key, err, tol, err <= tol))
+    out_tol = 2e-4 if f32 else 5e-2
+    for key in ('ctc_output', 'att_output'):
+        err = float(np.abs(res[key].detach().cpu().numpy() - z[key]).max())
+        report.append((key, err, out_tol, err <= out_tol))
+    gmax = max(float(z['gradnorm.' + k]) for k in sd)
+    for k, p in model.named_parameters():
+        r = float(z['gradnorm.' + k])
+        n = float(p.grad.norm())
+        tol = (5e-4 if f32 else 6e-2) * r + 1e-5 * gmax
+        report.append(('gradnorm.' + k, abs(n - r), tol, abs(n - r) <= tol))
+        if f32:
+            err = float(np.abs(p.grad.reshape(-1)[:8].cpu().numpy() - z['gradhead.' + k]).max())
+            tol = 3e-4 * r + 3e-6 * gmax        # conv biases in front of LayerNorm have a mathematically zero gradient: pure rounding noise
+            report.append(('gradhead.' + k, err, tol, err <= tol))
+    finish(report)
+
+
 def test_greedy_decoding_matches_reference(golden_dir):
     meta, z = load(golden_dir, 'g1_small_c2')
     cfg, sd, model = build(meta, 'fp32')

@@ -1,0 +1,49 @@
+"""Inference Solver (reference bin/test_asr.py:17-173): builds the ASR from the training config, loads the
+checkpoint, beam-decodes each split and writes the hypothesis TSV.  Decoding is batched over beams on the GPU."""
+import copy
+import os
+
+import torch
+import yaml
+
+from src.asr import ASR
+from src.data import load_dataset
+from src.decode import BeamDecoder
+from src.solver import BaseSolver
+
+
+class Solver(BaseSolver):
+    def __init__(self, config, paras, mode):
+        super().__init__(config, paras, mode)
+        os.makedirs(paras.outdir, exist_ok=True)
+        self.src_config = yaml.load(open(config['src']['config'], 'r'), Loader=yaml.FullLoader)
+        self.paras.load = config['src']['ckpt']
+        self.config['data'] = copy.deepcopy(self.src_config['data'])
+        self.config['data']['corpus']['batch_size'] = 1
+
+    def load_data(self):
+        audio = dict(self.config['data']['audio'])
+        self.dv_set, self.tt_set, self.feat_dim, self.vocab_size, self.tokenizer, msg = load_dataset(
+            self.paras.njobs, self.paras.gpu, self.paras.pin_memory, False, self.config['data']['corpus'], audio,
+            self.config['data']['text'])
+        self.verbose(msg)
+
+    def set_model(self):
+        hip = self.src_config.get('hip', {})
+        self.model = ASR(self.feat_dim, self.vocab_size, 1, prec=hip.get('prec', 'bf16'), **self.src_config['model']).to(self.device)
+        self.load_ckpt()
+        self.model.eval()
+        self.decoder = BeamDecoder(self.model, None, **self.config['decode'])
+        self.verbose(self.decoder.create_msg())
+
+    def exec(self):
+        for name, ds in (('dev', self.dv_set), ('test', self.tt_set)):
+            path = os.path.join(self.paras.outdir, '{}_{}.tsv'.format(self.exp_name, name))
+            with open(path, 'w') as f:
+                f.write('idx\thyp\ttruth\n')
+                for names, feat, feat_len, txt in ds:
+                    for b in range(feat.shape[0]):
+                        hyps = self.decoder(feat[b:b + 1, :int(feat_len[b])].to(self.device), feat_len[b:b + 1].to(self.device))
+                        hyp = self.tokenizer.decode(hyps[0].outIndex) if hyps else ''
+                        f.write('\t'.join([names[b], hyp, self.tokenizer.decode(txt[b].tolist())]) + '\n')
+            self.verbose('Wrote {}'.format(path))

@@ -338,6 +338,18 @@ __global__ __launch_bounds__(256) void dec_greedy_kernel(DecP p, int t) {
     }
 }
 
+__global__ __launch_bounds__(256) void dec_logits_kernel(DecP p, int t) {
+    const asr_dec_dims_t& d = p.d;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* h = p.s.hs + (((long)b * d.L + t) * d.NL + (d.NL - 1)) * d.Dd;
+    for (int v = wave; v < d.V; v += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < d.Dd; k += 64) acc += h[k] * p.w.Wc[(long)v * d.Dd + k];
+        acc = wave_sum(acc);
+        if (lane == 0) p.s.logits[((long)b * d.L + t) * d.V + v] = acc + p.w.bc[v];
+    }
+}
+
 // =================================================================================================
 // backward
 // =================================================================================================
@@ -760,6 +772,52 @@ extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_wei
                       (long)d.NL * d.Dd, d.Dd, d.V, 1, 1, ASR_ACT_NONE, 0, 1, 1, 0, 0, 0, 0, 0, prec, stream);
         if (rc != ASR_OK) return rc;
     }
+    return ASR_OK;
+}
+
+// One decode step t for every row of the state (beam search: rows = live hypotheses, all at the same step).
+// The caller has set state->tokens[:, t] (input token of the step) and, for t > 0, the step t-1 entries of
+// hs / cs / att of every row (parents' values after pruning).  Produces att[:, t], xin[:, t], gates/cs/hs[:, t]
+// and logits[:, t].  (state->key must hold tanh(proj_k(enc)) — asr_att_decoder_keys.)
+extern "C" int asr_att_decoder_keys(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights, const float* enc,
+                                    float* key, int prec, asr_stream_t stream) {
+    ASR_REQUIRE(dims && weights && enc && key, ASR_E_ARG, "asr_att_decoder_keys: null pointer");
+    const asr_dec_dims_t& d = *dims;
+    return asr_gemm(enc, weights->Wk, key, weights->bk, d.B * d.Tp, d.A, d.E, d.E, d.E, d.A, 1, 1, ASR_ACT_TANH, 0, 1, 1, 0, 0, 0, 0, 0,
+                    prec, stream);
+}
+
+extern "C" int asr_att_decoder_step(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights,
+                                    const float* enc, const int64_t* enc_len, const asr_dec_state_t* state, int t,
+                                    int prec, asr_stream_t stream) {
+    ASR_REQUIRE(dims && weights && enc && enc_len && state, ASR_E_ARG, "asr_att_decoder_step: null pointer");
+    const asr_dec_dims_t& d = *dims;
+    int rc = check_dims(d, "asr_att_decoder_step");
+    if (rc != ASR_OK) return rc;
+    ASR_REQUIRE(t >= 0 && t < d.L, ASR_E_ARG, "asr_att_decoder_step: step %d outside [0,%d)", t, d.L);
+    hipStream_t st = (hipStream_t)stream;
+    DecP p{d, *weights, *state, enc, enc_len};
+    const int XW = d.Dd + d.E;
+    const bool bf = (prec == ASR_BF16);
+    const int taps = 2 * d.Ks + 1;
+    const size_t lds_energy = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT);
+    const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
+    hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens, state->xin,
+                       d.B, d.L, d.Dd, XW, t, 1, d.V);
+    if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
+    else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
+    if (d.Kn <= 4)       hipLaunchKernelGGL(att_energy_kernel<4>, grid_tile, dim3(256), lds_energy, st, p, t);
+    else if (d.Kn <= 10) hipLaunchKernelGGL(att_energy_kernel<10>, grid_tile, dim3(256), lds_energy, st, p, t);
+    else                 hipLaunchKernelGGL(att_energy_kernel<16>, grid_tile, dim3(256), lds_energy, st, p, t);
+    hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
+    for (int l = 0; l < d.NL; ++l) {
+        if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
+        else    hipLaunchKernelGGL(dec_cell_fwd_kernel<false>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
+    }
+    // logits only (the arg-max side effect is redirected to a scratch row: t+1 >= L never written)
+    DecP pl = p;
+    hipLaunchKernelGGL(dec_logits_kernel, dim3(d.B), dim3(256), sizeof(float) * d.V, st, pl, t);
+    ASR_LAUNCH_CHECK("asr_att_decoder_step");
     return ASR_OK;
 }
 

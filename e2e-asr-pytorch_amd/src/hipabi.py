@@ -64,6 +64,12 @@ SIGNATURES = {
     'asr_ln_freq_fwd': [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp],
     'asr_ln_freq_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     'asr_permute_last2': [_vp, _vp, _l, _i, _i, _vp],
+    'asr_att_decoder_keys': [_P(DecDims), _P(DecWeights), _vp, _vp, _i, _vp],
+    'asr_att_decoder_step': [_P(DecDims), _P(DecWeights), _vp, _vp, _P(DecState), _i, _i, _vp],
+    'asr_ctc_prefix_init': [_vp, _vp, _i, _i, _vp],
+    'asr_ctc_prefix_score': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'asr_lstm_cell': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    'asr_gather_rows': [_vp, _vp, _vp, _i, _i, _l, _l, _i, _vp],
     'asr_sumsq': [_vp, _l, _vp, _vp],
     'asr_scale': [_vp, _l, _f, _vp],
     'asr_adadelta_step': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp],

@@ -1,0 +1,58 @@
+"""RNN language model for shallow fusion (reference src/lm.py:5-38): parameter container with the same names
+(`emb`, `rnn.weight_ih_l*`, `trans`) and a one-token `step` batched over hypotheses on the HIP path."""
+import torch
+import torch.nn as nn
+
+from src import hipabi as H
+from src.module import LSTMParams
+
+
+class RNNLM(nn.Module):
+    def __init__(self, vocab_size, emb_tying, emb_dim, module, dim, n_layers, dropout):
+        super().__init__()
+        if module.upper() != 'LSTM':
+            raise NotImplementedError('HIP path implements the LSTM language model')
+        self.dim, self.n_layers, self.emb_tying, self.vocab_size = dim, n_layers, emb_tying, vocab_size
+        if emb_tying:
+            assert emb_dim == dim, 'Output dim of RNN should be identical to embedding if using weight tying.'
+        self.emb = nn.Embedding(vocab_size, emb_dim)
+        self.rnn = LSTMParams(emb_dim, dim, False, num_layers=n_layers)
+        if not emb_tying:
+            self.trans = nn.Linear(emb_dim, vocab_size)
+        self.prec = H.BF16
+
+    def init_state(self, n, device):
+        z = lambda: torch.zeros((self.n_layers, n, self.dim), dtype=torch.float32, device=device)
+        return z(), z()
+
+    @torch.no_grad()
+    def step(self, tokens, state):
+        """tokens (n) int64 on the device, state = (h, c) each (layers, n, dim) -> (log-probs (n,V), new state)."""
+        n = tokens.shape[0]
+        dev = tokens.device
+        st = H.stream_ptr()
+        h_prev, c_prev = state
+        x = torch.empty((n, self.emb.weight.shape[1]), dtype=torch.float32, device=dev)
+        tok = tokens.contiguous()
+        H.call('asr_gather_rows', H.ptr(self.emb.weight), H.ptr(tok), H.ptr(x), n, x.shape[1], x.shape[1], x.shape[1],
+               self.vocab_size, st)
+        h_new, c_new = torch.empty_like(h_prev), torch.empty_like(c_prev)
+        for l in range(self.n_layers):
+            wih, whh = getattr(self.rnn, 'weight_ih_l%d' % l), getattr(self.rnn, 'weight_hh_l%d' % l)
+            pre = torch.empty((n, 4 * self.dim), dtype=torch.float32, device=dev)
+            H.gemm(x, wih, pre, n, 4 * self.dim, x.shape[1], x.shape[1], wih.shape[1], 4 * self.dim, 1, 1, prec=self.prec)
+            hp = h_prev[l].contiguous()
+            H.gemm(hp, whh, pre, n, 4 * self.dim, self.dim, self.dim, self.dim, 4 * self.dim, 1, 1, accum=1, prec=self.prec)
+            cp = c_prev[l].contiguous()
+            H.call('asr_lstm_cell', H.ptr(pre), H.ptr(getattr(self.rnn, 'bias_ih_l%d' % l)), H.ptr(getattr(self.rnn, 'bias_hh_l%d' % l)),
+                   H.ptr(cp), H.ptr(h_new[l]), H.ptr(c_new[l]), n, self.dim, st)
+            x = h_new[l]
+        logits = torch.empty((n, self.vocab_size), dtype=torch.float32, device=dev)
+        if self.emb_tying:
+            H.gemm(x, self.emb.weight, logits, n, self.vocab_size, self.dim, self.dim, self.dim, self.vocab_size, 1, 1, prec=self.prec)
+        else:
+            H.gemm(x, self.trans.weight, logits, n, self.vocab_size, self.dim, self.dim, self.dim, self.vocab_size, 1, 1,
+                   bias=self.trans.bias, prec=self.prec)
+        logp = torch.empty_like(logits)
+        H.call('asr_log_softmax', H.ptr(logits), H.ptr(logp), n, self.vocab_size, st)
+        return logp, (h_new, c_new)

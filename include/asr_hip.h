@@ -252,6 +252,33 @@ int asr_ln_freq_bwd(const float* dy, const float* x, const float* w, const float
                     float* dx, float* dw, float* db, long rows, int F, int C, int relu, asr_stream_t stream);
 int asr_permute_last2(const float* in, float* out, long rows, int A, int Bd, asr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Beam-search inference (BeamDecoder.forward src/decode.py:65-183), batched over live hypotheses.
+ *   asr_att_decoder_keys : key = tanh(proj_k(enc)) once per utterance (src/asr.py:345).
+ *   asr_att_decoder_step : ONE decode step t for all dims->B rows of `state` (each row = one hypothesis at step t):
+ *                          the caller sets state->tokens[:,t] and, for t>0, the step t-1 entries of hs/cs/att of
+ *                          every row; outputs att/xin/gates/cs/hs/logits[:,t]   (src/decode.py:107-116).
+ *   asr_ctc_prefix_init / asr_ctc_prefix_score : CTCPrefixScore.init_state / cheap_compute (src/ctc.py:19-27,68-107)
+ *                          for N hypotheses x C candidates: logp (T,V); r_prev (N,T,2); candidates (N,C) int32;
+ *                          prefix_len, last_token (N) int32; psi (N,C); r_out (N,C,T,2).  fp32, logzero = -1e8.
+ *   asr_lstm_cell        : pointwise LSTM cell on gate pre-activations (N,4D) + both biases (RNNLM step, src/lm.py:27-37;
+ *                          the projections are asr_gemm);  c_prev may be NULL (zero state).
+ *   asr_gather_rows      : dst[r,:] = src[idx[r],:]  (embedding lookup, state re-ordering after pruning).
+ */
+int asr_att_decoder_keys(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights, const float* enc,
+                         float* key, int prec, asr_stream_t stream);
+int asr_att_decoder_step(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights,
+                         const float* enc, const int64_t* enc_len, const asr_dec_state_t* state, int t,
+                         int prec, asr_stream_t stream);
+int asr_ctc_prefix_init(const float* logp, float* r, int T, int V, asr_stream_t stream);
+int asr_ctc_prefix_score(const float* logp, const float* r_prev, const int* candidates, const int* prefix_len,
+                         const int* last_token, float* psi, float* r_out, int N, int C, int T, int V,
+                         asr_stream_t stream);
+int asr_lstm_cell(const float* gates_pre, const float* bias_ih, const float* bias_hh, const float* c_prev,
+                  float* h, float* c, int N, int D, asr_stream_t stream);
+int asr_gather_rows(const float* src, const int64_t* idx, float* dst, int rows, int width, long src_ld, long dst_ld,
+                    int nsrc, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,61 @@
+"""Beam-search decoding on the HIP path vs the reference fixtures (tests/golden/g7_decode.npz): CTC prefix scores,
+and the hypotheses (token sequences + per-token scores) for attention-only, +CTC and +CTC+RNNLM decoding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def g7(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'g7_decode.npz'))
+    return yaml.safe_load(str(z['meta'])), z
+
+
+def test_ctc_prefix_scores_match_reference(g7):
+    from src.ctc import CTCPrefixScore
+    meta, z = g7
+    lp = torch.from_numpy(z['ctc_logp']).unsqueeze(0).cuda()
+    ps = CTCPrefixScore(lp)
+    r0 = ps.init_state()
+    np.testing.assert_allclose(r0.cpu().numpy(), z['r0'], rtol=1e-5, atol=1e-4)
+    cand = z['cand'].tolist()
+    psi1, r1 = ps.cheap_compute([], r0, cand)
+    np.testing.assert_allclose(psi1.cpu().numpy(), z['psi1'], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(r1.cpu().numpy(), z['r1'], rtol=2e-5, atol=2e-3)
+    psi2, r2 = ps.cheap_compute([7], r1[cand.index(7)], cand)
+    np.testing.assert_allclose(psi2.cpu().numpy(), z['psi2'], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(r2.cpu().numpy(), z['r2'], rtol=2e-5, atol=2e-3)
+    psi3, r3 = ps.cheap_compute([7, 7], r2[cand.index(7)], [7, 1, 3])
+    np.testing.assert_allclose(psi3.cpu().numpy(), z['psi3'], rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize('tag,ctc_w,lm_w', [('att', 0.0, 0.0), ('ctc', 0.3, 0.0), ('ctc_lm', 0.3, 0.5)])
+def test_beam_hypotheses_match_reference(g7, tag, ctc_w, lm_w):
+    from src.asr import ASR
+    from src.decode import BeamDecoder
+    from src.lm import RNNLM
+    meta, z = g7
+    cfg = O.ModelCfg(meta['model'], meta['D'], meta['V'])
+    model = ASR(meta['D'], meta['V'], 4, prec='fp32', **meta['model'])
+    model.load_state_dict(O.seeded_state_dict(O.param_shapes(cfg), meta['wseed']))
+    model = model.cuda().eval()
+    dec = BeamDecoder(model, None, beam_size=meta['beam'], min_len_ratio=meta['min_len_ratio'], max_len_ratio=meta['max_len_ratio'],
+                      ctc_weight=ctc_w)
+    if lm_w > 0:
+        lm = RNNLM(meta['V'], **meta['lm'])
+        shapes = {k: tuple(v.shape) for k, v in lm.state_dict().items()}
+        lm.load_state_dict(O.seeded_state_dict(shapes, meta['lm_wseed']))
+        dec.set_lm(lm.cuda().eval(), lm_w)
+    hyps = dec(torch.from_numpy(z['feat']).cuda(), torch.from_numpy(z['feat_len']).cuda())
+    assert len(hyps) == int(z['n_' + tag])
+    for i, h in enumerate(hyps):
+        assert h.outIndex == z['%s_seq%d' % (tag, i)].tolist(), (tag, i, h.outIndex, z['%s_seq%d' % (tag, i)].tolist())
+        np.testing.assert_allclose(np.array(h.output_scores, dtype=np.float32), z['%s_score%d' % (tag, i)], rtol=1e-4, atol=2e-3)
+        assert abs(h.avgScore() - float(z['%s_avg%d' % (tag, i)])) < 2e-3

@@ -11,6 +11,7 @@
 // Step kernels are bandwidth/latency bound: key (B,T',A) and enc (B,T',E) are re-read every step and
 // stay resident in the 256 MB Infinity Cache between steps; one launch covers the whole batch.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -56,9 +57,10 @@ __global__ void embed_kernel(const float* __restrict__ emb, const int64_t* __res
 // K1: query projection  q[b,t,:] = tanh(W_q hcat_{t-1}[b] + b_q);  one wave per 16 output columns
 // ------------------------------------------------------------------------------------------------
 template <bool BF16>
-__global__ __launch_bounds__(64) void dec_query_kernel(DecP p, int t) {
+__global__ __launch_bounds__(256) void dec_query_kernel(DecP p, int t) {
+    __shared__ float red[4][256];
     const asr_dec_dims_t& d = p.d;
-    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
     const int a = blockIdx.x * 16 + n;
     const bool aok = a < d.A;
     const float* wrow = p.w.Wq + (long)(aok ? a : 0) * d.Q;
@@ -69,13 +71,16 @@ __global__ __launch_bounds__(64) void dec_query_kernel(DecP p, int t) {
             const int ab = m0 + n;
             const bool rok = ab < d.B;
             const float* hrow = p.s.hs + ((long)(rok ? ab : 0) * d.L + (t - 1)) * d.Q;
-            acc = dot_rows<BF16>(hrow, rok, wrow, aok, d.Q, 0, 1, vec, acc);
+            acc = dot_rows<BF16>(hrow, rok, wrow, aok, d.Q, wave, 4, vec, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = m0 + 4 * q + r;
-            if (aok && b < d.B) p.s.q[((long)b * d.L + t) * d.A + a] = tanhf(acc[r] + p.w.bq[a]);
-        }
+        for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
+        __syncthreads();
+        const int row = tid >> 4, col = tid & 15;
+        const int b = m0 + row, ac = blockIdx.x * 16 + col;
+        if (b < d.B && ac < d.A)
+            p.s.q[((long)b * d.L + t) * d.A + ac] = tanhf(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] + p.w.bq[ac]);
+        __syncthreads();
     }
 }
 
@@ -363,6 +368,7 @@ struct DecB {
     float* dattn;      // (B,T')        scratch of the current step
     float* datt_next;  // (B,T')        gradient flowing into attn_t from step t+1's location conv
     float* dconv;      // (B,Kn,T')
+    float* dqpart;     // (B,ntiles,A)  per-workgroup partial sums of du over the tile's frames
     float* dcf;        // (NL,B,Dd)
     float* wcatT[ASR_MAX_DEC_LAYERS];  // ((Kx+Dd) x 4Dd) transposed [W_ih ; W_hh]
     float* wqT;        // (Q x A)
@@ -470,93 +476,134 @@ __global__ __launch_bounds__(256) void att_bwd_dattn_kernel(DecB p, int t, int l
     }
 }
 
-// B2b: softmax backward + energy backward for one (utterance, 64-frame tile)
+// B2b: softmax backward + energy backward for one (utterance, TT-frame tile).
+// Block = ceil(A/64) waves; wave w OWNS attention dims a = 64w + lane for all TT frames of the tile, so the
+// per-a partial sums (d w_g, d W_proj, d query) have exactly one writer — no atomics (LDS float atomics were
+// measured at ~0.2 us per wave-instruction and dominated this kernel).
 template <int KNMAX>
-__global__ __launch_bounds__(256) void att_bwd_energy_kernel(DecB p, int t) {
+__global__ __launch_bounds__(512) void att_bwd_energy_kernel(DecB p, int t, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    __shared__ float s4[4];
+    __shared__ float s16[16];
     __shared__ float s_de[TT];
     const asr_dec_dims_t& d = p.f.d;
     const int b = blockIdx.y, tau0 = blockIdx.x * TT;
+    const int nthr = blockDim.x, nwave = nthr >> 6;
     const int taps = 2 * d.Ks + 1;
     const int AP = d.A | 1;                        // odd row stride of the dloc tile (bank spread)
     float* s_pa = smem_f;
     float* s_wc = s_pa + (TT + 2 * d.Ks);
     float* s_conv = s_wc + d.Kn * taps;
-    float* s_part = s_conv + d.Kn * TT;            // [A*(1+Kn)] block partial sums: d w_g, d W_proj
-    float* s_dl = s_part + d.A * (1 + d.Kn);       // [TT*AP] gradient wrt the loc pre-activation
-    conv_tile(p.f, b, t, tau0, s_pa, s_wc, s_conv);
+    float* s_dl = s_conv + d.Kn * TT;              // [TT*AP] gradient wrt the loc pre-activation
+    float* s_wp = s_dl + TT * AP;                  // [A*Kn] W_proj staged once per workgroup
+    float* s_dcw = s_wp + d.A * d.Kn;              // [nwave][Kn*TT] per-wave partial dconv
+    if (!(dbg & 1)) conv_tile(p.f, b, t, tau0, s_pa, s_wc, s_conv);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = min((int)p.f.enc_len[b], d.Tp);
     const float* att = p.f.s.att + ((long)b * d.L + t) * d.Tp;
     const float* dat = p.dattn + (long)b * d.Tp;
     // softmax backward needs sum_tau attn*dattn over the whole utterance
     float dot = 0.f;
-    for (int i = threadIdx.x; i < len; i += 256) dot += att[i] * dat[i];
-    dot = block_sum(dot, s4);
-    if (threadIdx.x < TT) {
-        const int tau = tau0 + threadIdx.x;
-        s_de[threadIdx.x] = (tau < len) ? att[tau] * (dat[tau] - dot) / d.temperature : 0.f;
+    for (int i = tid; i < len; i += nthr) dot += att[i] * dat[i];
+    dot = wave_sum(dot);
+    if (lane == 0) s16[wave] = dot;
+    for (int i = tid; i < d.A * d.Kn; i += nthr) s_wp[i] = p.f.w.Wproj[i];
+    __syncthreads();
+    dot = 0.f;
+    for (int w = 0; w < nwave; ++w) dot += s16[w];
+    if (tid < TT) {
+        const int tau = tau0 + tid;
+        s_de[tid] = (tau < len) ? att[tau] * (dat[tau] - dot) / d.temperature : 0.f;
     }
-    for (int i = threadIdx.x; i < d.A * (1 + d.Kn); i += 256) s_part[i] = 0.f;
     __syncthreads();
 
-    const float* qrow = p.f.s.q + ((long)b * d.L + t) * d.A;
-    float* dqrow = p.dq + ((long)b * d.L + t) * d.A;
+    const int a = 64 * wave + lane;
+    const bool aok = a < d.A;
+    const int ac = aok ? a : d.A - 1;
     const int tmax = max(len - 1, 0);
-    for (int a = lane; a < d.A; a += 64) {
+    float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot;
+    if (!(dbg & 2)) {
+        // every key / dkey element of this lane's column: 2*TT loads in flight, no further global reads in the loop
+        float kv[TT], dk[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const long ki = ((long)b * d.Tp + min(tau0 + i, tmax)) * d.A + ac;
+            kv[i] = (dbg & 128) ? 0.5f : p.f.s.key[ki];
+            dk[i] = (dbg & 128) ? 0.25f : p.dkey[ki];
+        }
         float wp[KNMAX], dwp[KNMAX];
 #pragma unroll
-        for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? p.f.w.Wproj[(long)a * d.Kn + k] : 0.f; dwp[k] = 0.f; }
-        const float qa = qrow[a], wga = p.f.w.wg[a];
+        for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? s_wp[ac * d.Kn + k] : 0.f; dwp[k] = 0.f; }
+        const float qa = p.f.s.q[((long)b * d.L + t) * d.A + ac], wga = p.f.w.wg[ac];
         float dwg = 0.f, dqa = 0.f;
-        float kv[TPW], dk[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {   // key and dkey of this column in flight together
-            const long ki = ((long)b * d.Tp + min(tau0 + wave * TPW + i, tmax)) * d.A + a;
-            kv[i] = p.f.s.key[ki];
-            dk[i] = p.dkey[ki];
-        }
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int ti = wave * TPW + i;
-            const int tau = tau0 + ti;
+        for (int i = 0; i < TT; ++i) {
+            const int tau = tau0 + i;
             float lp = 0.f;
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
+            for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + i];
             const float loc = tanh_fast(lp);
             const float u = tanh_fast(kv[i] + qa + loc);
-            const float de = s_de[ti];                      // 0 for tau >= len
+            const float de = s_de[i];                       // 0 for tau >= len
             const float du = de * wga * (1.f - u * u);
             const float dl = du * (1.f - loc * loc);
             dwg += de * u;
             dqa += du;
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + ti];
-            if (tau < len) p.dkey[((long)b * d.Tp + tau) * d.A + a] = dk[i] + du;
-            s_dl[ti * AP + a] = dl;
+            for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + i];
+            if (aok && tau < len && !(dbg & 32)) p.dkey[((long)b * d.Tp + tau) * d.A + a] = dk[i] + du;
+            if (aok) s_dl[i * AP + a] = dl;
         }
-        atomicAdd(&s_part[a], dwg);
+        if (aok && !(dbg & 16)) {
+            // single owner of (a): per-workgroup slot accumulated across steps, query partial of this step
+            // (all loads first, then all stores: a chain of `slot[i] += x` is a chain of dependent round trips)
+            float old[KNMAX + 1];
+            old[KNMAX] = slot[a];
 #pragma unroll
-        for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) atomicAdd(&s_part[d.A + a * d.Kn + k], dwp[k]);
-        atomicAdd(&dqrow[a], dqa);
+            for (int k = 0; k < KNMAX; ++k) old[k] = (k < d.Kn && !(dbg & 256)) ? slot[d.A + k * d.A + a] : 0.f;   // [k][a]: lanes contiguous
+            slot[a] = old[KNMAX] + dwg;
+#pragma unroll
+            for (int k = 0; k < KNMAX; ++k) if (k < d.Kn && !(dbg & 512)) slot[d.A + k * d.A + a] = old[k] + dwp[k];
+            if (!(dbg & 1024)) p.dqpart[((long)b * p.ntiles + blockIdx.x) * d.A + a] = dqa;
+        }
     }
     __syncthreads();
-    // dconv[tau,k] = sum_a dl[tau,a] * Wproj[a,k]
-    for (int o = threadIdx.x; o < d.Kn * TT; o += 256) {
-        const int ti = o % TT, k = o / TT;
-        const int tau = tau0 + ti;
-        float acc = 0.f;
-        if (tau < len) for (int a = 0; a < d.A; ++a) acc += s_dl[ti * AP + a] * p.f.w.Wproj[(long)a * d.Kn + k];
-        if (tau < d.Tp) p.dconv[((long)b * d.Kn + k) * d.Tp + tau] = acc;
+    // dconv[tau,k] = sum_a dl[tau,a] * Wproj[a,k]: thread (frame ti = lane % TT, chunk = wave*(64/TT) + lane / TT)
+    {
+        constexpr int CPW = 64 / TT;                  // chunks per wave
+        const int nch = nwave * CPW;
+        const int ti = lane % TT, ch = wave * CPW + lane / TT;
+        const int a_per = (d.A + nch - 1) / nch;
+        const int a_beg = ch * a_per, a_end = min(d.A, a_beg + a_per);
+        float acc[KNMAX];
+#pragma unroll
+        for (int k = 0; k < KNMAX; ++k) acc[k] = 0.f;
+        for (int x = a_beg; x < a_end && !(dbg & 4); ++x) {
+            const float dl = s_dl[ti * AP + x];
+#pragma unroll
+            for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) acc[k] += dl * s_wp[x * d.Kn + k];
+        }
+#pragma unroll
+        for (int k = 0; k < KNMAX; ++k) {
+            float v = acc[k];
+            for (int o = TT; o < 64; o <<= 1) v += __shfl_xor(v, o);      // the wave's chunks
+            if (k < d.Kn && lane < TT) s_dcw[(wave * d.Kn + k) * TT + ti] = v;
+        }
+        __syncthreads();
+        for (int o = tid; o < d.Kn * TT; o += nthr) {
+            const int t2 = o % TT, k = o / TT;
+            float v = 0.f;
+            for (int w = 0; w < nwave; ++w) v += s_dcw[(w * d.Kn + k) * TT + t2];
+            const int tau = tau0 + t2;
+            if (tau < d.Tp) p.dconv[((long)b * d.Kn + k) * d.Tp + tau] = (tau < len) ? v : 0.f;
+        }
     }
-    // per-workgroup partial sums, accumulated across steps in this workgroup's private slot
-    float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot;
-    for (int i = threadIdx.x; i < d.A * (1 + d.Kn); i += 256) slot[i] += s_part[i];
-    float sde = (threadIdx.x < TT) ? s_de[threadIdx.x] : 0.f;
-    sde = block_sum(sde, s4);
-    if (threadIdx.x == 0) slot[d.A * (1 + d.Kn)] += sde;
+    // d b_g partial
+    if (tid < 64) {
+        float sde = (tid < TT) ? s_de[tid] : 0.f;
+        sde = wave_sum(sde);
+        if (tid == 0) slot[d.A * (1 + d.Kn)] += sde;
+    }
 }
 
 // B2c: gradient through the location convolution: datt_next (wrt attn_{t-1}) and d W_conv partials
@@ -609,21 +656,47 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(DecB p, int t) {
             p.datt_next[(long)b * d.Tp + tau] = v;
         }
     }
-    // d W_conv[k][j] += sum_{tau in tile} dconv[k][tau] * pa[tau + j - Ks]
+    // d W_conv[k][j] += sum_{tau in tile} dconv[k][tau] * pa[tau + j - Ks]   (sums first, then one batched read-modify-write)
     float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot + d.A * (1 + d.Kn) + 1;
-    for (int o = threadIdx.x; o < d.Kn * taps; o += 256) {
-        const int k = o / taps, j = o % taps;
-        float acc = 0.f;
-        for (int i = 0; i < TT; ++i) acc += s_dc[k * win + d.Ks + i] * s_pa[i + j];
-        slot[o] += acc;
+    constexpr int NO = 10;                         // outputs per thread per pass
+    for (int o0 = threadIdx.x; o0 < d.Kn * taps; o0 += 256 * NO) {
+        float acc[NO], old[NO];
+#pragma unroll
+        for (int u = 0; u < NO; ++u) {
+            const int o = o0 + 256 * u;
+            acc[u] = 0.f;
+            if (o < d.Kn * taps) {
+                const int k = o / taps, j = o % taps;
+                float a = 0.f;
+                for (int i = 0; i < TT; ++i) a += s_dc[k * win + d.Ks + i] * s_pa[i + j];
+                acc[u] = a;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NO; ++u) { const int o = o0 + 256 * u; old[u] = (o < d.Kn * taps) ? slot[o] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < NO; ++u) { const int o = o0 + 256 * u; if (o < d.Kn * taps) slot[o] = old[u] + acc[u]; }
     }
 }
 
-// B3: query backward.  dq[b,t,:] <- dq * (1 - q^2);  dhs[b,t-1,:] += that * W_q   (one wave per 16 columns of Q)
-template <bool BF16>
-__global__ __launch_bounds__(64) void dec_query_bwd_kernel(DecB p, int t) {
+// B3: query backward.  dq[b,t,:] <- dq * (1 - q^2) (kept for the batched dW_q);  dhs[b,t-1,:] += that * W_q.
+__global__ void dq_pre_kernel(DecB p, int t) {
     const asr_dec_dims_t& d = p.f.d;
-    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.B * d.A) return;
+    const int b = i / d.A, a = i % d.A;
+    const long idx = ((long)b * d.L + t) * d.A + a;
+    const float qv = p.f.s.q[idx];
+    float acc = 0.f;
+#pragma unroll 8
+    for (int tl = 0; tl < p.ntiles; ++tl) acc += p.dqpart[((long)b * p.ntiles + tl) * d.A + a];
+    p.dq[idx] = acc * (1.f - qv * qv);
+}
+template <bool BF16>
+__global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t) {
+    __shared__ float red[4][256];
+    const asr_dec_dims_t& d = p.f.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
     const int c = blockIdx.x * 16 + n;
     const bool cok = c < d.Q;
     const float* wrow = p.wqT + (long)(cok ? c : 0) * d.A;
@@ -632,21 +705,16 @@ __global__ __launch_bounds__(64) void dec_query_bwd_kernel(DecB p, int t) {
         const bool rok = ab < d.B;
         const float* drow = p.dq + ((long)(rok ? ab : 0) * d.L + t) * d.A;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = dot_rows<BF16>(drow, rok, wrow, cok, d.A, 0, 1, (d.A % 4) == 0, acc);
+        acc = dot_rows<BF16>(drow, rok, wrow, cok, d.A, wave, 4, (d.A % 4) == 0, acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = m0 + 4 * q + r;
-            if (cok && b < d.B) p.dhs[((long)b * d.L + (t - 1)) * d.Q + c] += acc[r];
-        }
+        for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
+        __syncthreads();
+        const int row = tid >> 4, col = tid & 15;
+        const int b = m0 + row, cc = blockIdx.x * 16 + col;
+        if (b < d.B && cc < d.Q)
+            p.dhs[((long)b * d.L + (t - 1)) * d.Q + cc] += red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        __syncthreads();
     }
-}
-__global__ void dq_pre_kernel(DecB p, int t) {
-    const asr_dec_dims_t& d = p.f.d;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.B * d.A) return;
-    const long idx = ((long)(i / d.A) * d.L + t) * d.A + (i % d.A);
-    const float qv = p.f.s.q[idx];
-    p.dq[idx] *= (1.f - qv * qv);
 }
 
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, long ld_dst, long col0) {
@@ -658,31 +726,39 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
     }
 }
 
-// reduce the per-workgroup slots into the parameter gradients
-__global__ void slot_reduce_kernel(const float* __restrict__ slots, int nslots, int slot, float* __restrict__ out, int off, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// reduce the per-workgroup slots into the parameter gradients: one wave per output element
+__global__ __launch_bounds__(256) void slot_reduce_kernel(const float* __restrict__ slots, int nslots, int slot, float* __restrict__ out,
+                                                          int off, int n, int tr_rows, int tr_cols) {
+    // tr_rows > 0: the slot holds this block transposed ([col][row]) and `out` is [row][col]
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= n) return;
+    const int src = tr_rows > 0 ? (i % tr_cols) * tr_rows + (i / tr_cols) : i;
     float acc = 0.f;
-    for (int s = 0; s < nslots; ++s) acc += slots[(long)s * slot + off + i];
-    out[i] += acc;
+    for (int s = lane; s < nslots; s += 64) acc += slots[(long)s * slot + off + src];
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] += acc;
 }
 
 // embedding gradient: dE[v,:] += sum over (b,t) with tokens[b,t] == v of dxin[b,t,0:Dd]   (deterministic)
-__global__ void embed_bwd_kernel(const float* __restrict__ dxin, const int64_t* __restrict__ tokens, float* __restrict__ demb,
-                                 int B, int L, int Dd, int XW, int V) {
-    const int v = blockIdx.x;
-    for (int k = threadIdx.x; k < Dd; k += blockDim.x) {
-        float acc = 0.f;
-        for (int i = 0; i < B * L; ++i)
+// grid (V, ceil(Dd/64)); 4 waves split the B*L positions, lanes over 64 columns
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dxin, const int64_t* __restrict__ tokens,
+                                                        float* __restrict__ demb, int B, int L, int Dd, int XW, int V) {
+    __shared__ float red[4][64];
+    const int v = blockIdx.x, k = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (k < Dd)
+        for (int i = grp; i < B * L; i += 4)
             if (tokens[i] == v) acc += dxin[(long)i * XW + k];
-        demb[(long)v * Dd + k] += acc;
-    }
+    red[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && k < Dd) demb[(long)v * Dd + k] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdLayout {
-    size_t dhs, dxin, dq, dkey, dattn, datt_next, dconv, dcf, wq_t, slots, dkeypre, wcat[ASR_MAX_DEC_LAYERS], total;
+    size_t dhs, dxin, dq, dkey, dattn, datt_next, dconv, dcf, wq_t, slots, dkeypre, dqpart, wcat[ASR_MAX_DEC_LAYERS], total;
     int ntiles, slot;
 };
 BwdLayout bwd_layout(const asr_dec_dims_t& d) {
@@ -700,6 +776,7 @@ BwdLayout bwd_layout(const asr_dec_dims_t& d) {
     o.dattn = take((size_t)d.B * d.Tp);
     o.datt_next = take((size_t)d.B * d.Tp);
     o.dconv = take((size_t)d.B * d.Kn * d.Tp);
+    o.dqpart = take((size_t)d.B * o.ntiles * d.A);
     o.dcf = take((size_t)d.NL * d.B * d.Dd);
     o.wq_t = take((size_t)d.Q * d.A);
     o.slots = take((size_t)d.B * o.ntiles * o.slot);
@@ -753,8 +830,8 @@ extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_wei
         if (!teacher)
             hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens,
                                state->xin, d.B, d.L, d.Dd, XW, t, 1, d.V);
-        if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
-        else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
+        if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
+        else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
         if (d.Kn <= 4)       hipLaunchKernelGGL(att_energy_kernel<4>, grid_tile, dim3(256), lds_energy, st, p, t);
         else if (d.Kn <= 10) hipLaunchKernelGGL(att_energy_kernel<10>, grid_tile, dim3(256), lds_energy, st, p, t);
         else                 hipLaunchKernelGGL(att_energy_kernel<16>, grid_tile, dim3(256), lds_energy, st, p, t);
@@ -804,8 +881,8 @@ extern "C" int asr_att_decoder_step(const asr_dec_dims_t* dims, const asr_dec_we
     const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
     hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens, state->xin,
                        d.B, d.L, d.Dd, XW, t, 1, d.V);
-    if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
-    else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(64), 0, st, p, t);
+    if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
+    else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
     if (d.Kn <= 4)       hipLaunchKernelGGL(att_energy_kernel<4>, grid_tile, dim3(256), lds_energy, st, p, t);
     else if (d.Kn <= 10) hipLaunchKernelGGL(att_energy_kernel<10>, grid_tile, dim3(256), lds_energy, st, p, t);
     else                 hipLaunchKernelGGL(att_energy_kernel<16>, grid_tile, dim3(256), lds_energy, st, p, t);
@@ -850,14 +927,13 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     p.g = *grads;
     p.dhs = (float*)(ws + lay.dhs); p.dxin = (float*)(ws + lay.dxin); p.dq = (float*)(ws + lay.dq);
     p.dkey = (float*)(ws + lay.dkey); p.dattn = (float*)(ws + lay.dattn); p.datt_next = (float*)(ws + lay.datt_next);
-    p.dconv = (float*)(ws + lay.dconv); p.dcf = (float*)(ws + lay.dcf); p.wqT = (float*)(ws + lay.wq_t);
+    p.dconv = (float*)(ws + lay.dconv); p.dqpart = (float*)(ws + lay.dqpart); p.dcf = (float*)(ws + lay.dcf); p.wqT = (float*)(ws + lay.wq_t);
     p.slots = (float*)(ws + lay.slots); p.ntiles = lay.ntiles; p.slot = lay.slot;
     float* dkeypre = (float*)(ws + lay.dkeypre);
     for (int l = 0; l < ASR_MAX_DEC_LAYERS; ++l) p.wcatT[l] = (l < d.NL) ? (float*)(ws + lay.wcat[l]) : nullptr;
 
     // zero-initialised accumulators: dhs, dq, dkey, slots  (dxin is fully written by the loop)
     hipMemsetAsync(p.dhs, 0, sizeof(float) * (size_t)BL * SW, st);
-    hipMemsetAsync(p.dq, 0, sizeof(float) * (size_t)BL * d.A, st);
     hipMemsetAsync(p.dkey, 0, sizeof(float) * (size_t)d.B * d.Tp * d.A, st);
     hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * lay.ntiles * lay.slot, st);
 
@@ -883,8 +959,10 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
 
     const int taps = 2 * d.Ks + 1;
     const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
-    const size_t lds_e = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT + (size_t)d.A * (1 + d.Kn) +
-                                          (size_t)TT * (d.A | 1));
+    const int nw_e = cdiv(d.A, 64);
+    ASR_REQUIRE(nw_e <= 8, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: attention dim %d > 512", d.A);
+    const size_t lds_e = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT + (size_t)TT * (d.A | 1) +
+                                          (size_t)d.A * d.Kn + (size_t)nw_e * d.Kn * TT);
     const size_t lds_c = sizeof(float) * ((size_t)d.Kn * taps + (size_t)(d.Kn + 1) * (TT + 2 * d.Ks));
     ASR_REQUIRE(lds_e <= 160 * 1024 - 1024, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: attention dim %d needs %zu B of LDS", d.A, lds_e);
     static bool attr_set = false;
@@ -895,6 +973,8 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         attr_set = true;
     }
 
+    const char* dbg_env = getenv("ASR_DEBUG_SKIP");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;      // timing ablation only (results are wrong when set)
     for (int t = d.L - 1; t >= 0; --t) {
         const int last = (t == d.L - 1);
         for (int l = d.NL - 1; l >= 0; --l) {
@@ -904,14 +984,14 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
             else    hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<false>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
         }
         hipLaunchKernelGGL(att_bwd_dattn_kernel, grid_tile, dim3(256), sizeof(float) * d.E, st, p, t, last);
-        if (d.Kn <= 4)       hipLaunchKernelGGL(att_bwd_energy_kernel<4>, grid_tile, dim3(256), lds_e, st, p, t);
-        else if (d.Kn <= 10) hipLaunchKernelGGL(att_bwd_energy_kernel<10>, grid_tile, dim3(256), lds_e, st, p, t);
-        else                 hipLaunchKernelGGL(att_bwd_energy_kernel<16>, grid_tile, dim3(256), lds_e, st, p, t);
+        if (d.Kn <= 4)       hipLaunchKernelGGL(att_bwd_energy_kernel<4>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
+        else if (d.Kn <= 10) hipLaunchKernelGGL(att_bwd_energy_kernel<10>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
+        else                 hipLaunchKernelGGL(att_bwd_energy_kernel<16>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
         hipLaunchKernelGGL(att_bwd_conv_kernel, grid_tile, dim3(256), lds_c, st, p, t);
         hipLaunchKernelGGL(dq_pre_kernel, dim3(cdiv(d.B * d.A, 256)), dim3(256), 0, st, p, t);
         if (t > 0) {
-            if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(64), 0, st, p, t);
-            else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(64), 0, st, p, t);
+            if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);
+            else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);
         }
     }
     ASR_LAUNCH_CHECK("asr_att_decoder_bwd");
@@ -939,7 +1019,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     rc = asr_colsum(p.dq, d.A, BL, d.A, grads->bq, stream);
     if (rc != ASR_OK) return rc;
     // embedding
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(d.V), dim3(256), 0, st, p.dxin, state->tokens, grads->emb, d.B, d.L, d.Dd, XW, d.V);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(d.V, cdiv(d.Dd, 64)), dim3(256), 0, st, p.dxin, state->tokens, grads->emb, d.B, d.L, d.Dd, XW, d.V);
     // context: denc[b] += attn[b]^T (T' x L) dctx[b] (L x E)
     rc = asr_gemm(state->att, p.dxin + d.Dd, denc, nullptr, d.Tp, d.E, d.L, d.Tp, XW, d.E, 0, 0, ASR_ACT_NONE, 1, 1, d.B,
                   (long)d.L * d.Tp, (long)d.L * XW, (long)d.Tp * d.E, 0, 0, prec, stream);
@@ -957,11 +1037,11 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     if (rc != ASR_OK) return rc;
     // slot partials -> d w_g, d W_proj, d b_g, d W_conv
     const int nslots = d.B * lay.ntiles;
-    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A, 256)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->wg, 0, d.A);
-    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A * d.Kn, 256)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wproj, d.A, d.A * d.Kn);
-    hipLaunchKernelGGL(slot_reduce_kernel, dim3(1), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->bg, d.A * (1 + d.Kn), 1);
-    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.Kn * taps, 256)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wconv,
-                       d.A * (1 + d.Kn) + 1, d.Kn * taps);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->wg, 0, d.A, 0, 0);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A * d.Kn, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wproj, d.A, d.A * d.Kn, d.A, d.Kn);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(1), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->bg, d.A * (1 + d.Kn), 1, 0, 0);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.Kn * taps, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wconv,
+                       d.A * (1 + d.Kn) + 1, d.Kn * taps, 0, 0);
     ASR_LAUNCH_CHECK("asr_att_decoder_bwd(tail)");
     return ASR_OK;
 }

@@ -523,48 +523,52 @@ __global__ __launch_bounds__(512) void att_bwd_energy_kernel(DecB p, int t, int 
     const int tmax = max(len - 1, 0);
     float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot;
     if (!(dbg & 2)) {
-        // every key / dkey element of this lane's column: 2*TT loads in flight, no further global reads in the loop
-        float kv[TT], dk[TT];
-#pragma unroll
-        for (int i = 0; i < TT; ++i) {
-            const long ki = ((long)b * d.Tp + min(tau0 + i, tmax)) * d.A + ac;
-            kv[i] = (dbg & 128) ? 0.5f : p.f.s.key[ki];
-            dk[i] = (dbg & 128) ? 0.25f : p.dkey[ki];
-        }
         float wp[KNMAX], dwp[KNMAX];
 #pragma unroll
         for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? s_wp[ac * d.Kn + k] : 0.f; dwp[k] = 0.f; }
         const float qa = p.f.s.q[((long)b * d.L + t) * d.A + ac], wga = p.f.w.wg[ac];
         float dwg = 0.f, dqa = 0.f;
+        constexpr int HALF = TT / 2;
+#pragma unroll 1
+        for (int h0 = 0; h0 < TT; h0 += HALF) {
+            // key / dkey of this lane's column for HALF frames: all loads in flight, no other global reads in the loop
+            float kv[HALF], dk[HALF];
 #pragma unroll
-        for (int i = 0; i < TT; ++i) {
-            const int tau = tau0 + i;
-            float lp = 0.f;
+            for (int i = 0; i < HALF; ++i) {
+                const long ki = ((long)b * d.Tp + min(tau0 + h0 + i, tmax)) * d.A + ac;
+                kv[i] = p.f.s.key[ki];
+                dk[i] = p.dkey[ki];
+            }
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + i];
-            const float loc = tanh_fast(lp);
-            const float u = tanh_fast(kv[i] + qa + loc);
-            const float de = s_de[i];                       // 0 for tau >= len
-            const float du = de * wga * (1.f - u * u);
-            const float dl = du * (1.f - loc * loc);
-            dwg += de * u;
-            dqa += du;
+            for (int i = 0; i < HALF; ++i) {
+                const int ti = h0 + i, tau = tau0 + ti;
+                float lp = 0.f;
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + i];
-            if (aok && tau < len && !(dbg & 32)) p.dkey[((long)b * d.Tp + tau) * d.A + a] = dk[i] + du;
-            if (aok) s_dl[i * AP + a] = dl;
+                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
+                const float loc = tanh_fast(lp);
+                const float u = tanh_fast(kv[i] + qa + loc);
+                const float de = s_de[ti];                       // 0 for tau >= len
+                const float du = de * wga * (1.f - u * u);
+                const float dl = du * (1.f - loc * loc);
+                dwg += de * u;
+                dqa += du;
+#pragma unroll
+                for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + ti];
+                if (aok && tau < len) p.dkey[((long)b * d.Tp + tau) * d.A + a] = dk[i] + du;
+                if (aok) s_dl[ti * AP + a] = dl;
+            }
         }
-        if (aok && !(dbg & 16)) {
+        if (aok) {
             // single owner of (a): per-workgroup slot accumulated across steps, query partial of this step
             // (all loads first, then all stores: a chain of `slot[i] += x` is a chain of dependent round trips)
             float old[KNMAX + 1];
             old[KNMAX] = slot[a];
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) old[k] = (k < d.Kn && !(dbg & 256)) ? slot[d.A + k * d.A + a] : 0.f;   // [k][a]: lanes contiguous
+            for (int k = 0; k < KNMAX; ++k) old[k] = (k < d.Kn) ? slot[d.A + k * d.A + a] : 0.f;   // [k][a]: lanes contiguous
             slot[a] = old[KNMAX] + dwg;
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) if (k < d.Kn && !(dbg & 512)) slot[d.A + k * d.A + a] = old[k] + dwp[k];
-            if (!(dbg & 1024)) p.dqpart[((long)b * p.ntiles + blockIdx.x) * d.A + a] = dqa;
+            for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) slot[d.A + k * d.A + a] = old[k] + dwp[k];
+            p.dqpart[((long)b * p.ntiles + blockIdx.x) * d.A + a] = dqa;
         }
     }
     __syncthreads();
@@ -680,17 +684,24 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(DecB p, int t) {
 }
 
 // B3: query backward.  dq[b,t,:] <- dq * (1 - q^2) (kept for the batched dW_q);  dhs[b,t-1,:] += that * W_q.
-__global__ void dq_pre_kernel(DecB p, int t) {
+__global__ __launch_bounds__(256) void dq_pre_kernel(DecB p, int t) {
+    // grid (ceil(A/64), B): 4 waves split the tiles of the utterance, lanes over 64 attention dims
+    __shared__ float red[4][64];
     const asr_dec_dims_t& d = p.f.d;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.B * d.A) return;
-    const int b = i / d.A, a = i % d.A;
-    const long idx = ((long)b * d.L + t) * d.A + a;
-    const float qv = p.f.s.q[idx];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int a = blockIdx.x * 64 + lane;
     float acc = 0.f;
-#pragma unroll 8
-    for (int tl = 0; tl < p.ntiles; ++tl) acc += p.dqpart[((long)b * p.ntiles + tl) * d.A + a];
-    p.dq[idx] = acc * (1.f - qv * qv);
+    if (a < d.A) {
+#pragma unroll 4
+        for (int tl = grp; tl < p.ntiles; tl += 4) acc += p.dqpart[((long)b * p.ntiles + tl) * d.A + a];
+    }
+    red[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && a < d.A) {
+        const long idx = ((long)b * d.L + t) * d.A + a;
+        const float qv = p.f.s.q[idx];
+        p.dq[idx] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * (1.f - qv * qv);
+    }
 }
 template <bool BF16>
 __global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t) {
@@ -988,7 +999,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         else if (d.Kn <= 10) hipLaunchKernelGGL(att_bwd_energy_kernel<10>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
         else                 hipLaunchKernelGGL(att_bwd_energy_kernel<16>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
         hipLaunchKernelGGL(att_bwd_conv_kernel, grid_tile, dim3(256), lds_c, st, p, t);
-        hipLaunchKernelGGL(dq_pre_kernel, dim3(cdiv(d.B * d.A, 256)), dim3(256), 0, st, p, t);
+        hipLaunchKernelGGL(dq_pre_kernel, dim3(cdiv(d.A, 64), d.B), dim3(256), 0, st, p, t);
         if (t > 0) {
             if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);
             else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);

@@ -151,17 +151,28 @@ int lstm_fwd_persistent(float* gates, const float* whh, const float* bias2, floa
 int lstm_bwd_persistent(float* gates, const float* whh, const float* dy, const float* c,
                         int B, int T, int H, int ND, int prec, void* ws, size_t ws_bytes, hipStream_t st);
 size_t lstm_persist_workspace_bytes(int B, int H, int ND);
+// lstm_persist2.hip (bf16, B <= 16, H % 16 == 0)
+int lstm_fwd_persistent2(float* gates, const float* whh, const float* bias2, float* y, float* c,
+                         int B, int T, int H, int ND, int prec, void* ws, size_t ws_bytes, hipStream_t st);
+int lstm_bwd_persistent2(float* gates, const float* whh, const float* dy, const float* c,
+                         int B, int T, int H, int ND, int prec, void* ws, size_t ws_bytes, hipStream_t st);
+size_t lstm_persist2_workspace_bytes(int B, int H, int ND);
 
+// 0: one launch per time step; 1: persistent kernels (lstm_persist2.hip where it applies, else lstm_persist.hip);
+// 2: persistent, first-generation kernels only.  Env ASR_LSTM_PERSIST gives the initial value.
 static int g_persist = -1;
-static bool persist_enabled() {
-    if (g_persist < 0) { const char* e = getenv("ASR_LSTM_PERSIST"); g_persist = (e && e[0] == '0') ? 0 : 1; }
-    return g_persist == 1;
+static int persist_mode() {
+    if (g_persist < 0) { const char* e = getenv("ASR_LSTM_PERSIST"); g_persist = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
+    return g_persist;
 }
-extern "C" int asr_lstm_set_persistent(int on) { int old = persist_enabled() ? 1 : 0; g_persist = on ? 1 : 0; return old; }
+static bool persist_enabled() { return persist_mode() >= 1; }
+extern "C" int asr_lstm_set_persistent(int on) { int old = persist_mode(); g_persist = (on >= 0 && on <= 2) ? on : 1; return old; }
 
 extern "C" size_t asr_lstm_workspace_bytes(int B, int H, int ND) {
     size_t step = ((size_t)ND * H * 4 * H + (size_t)ND * B * H) * sizeof(float);
     size_t per = lstm_persist_workspace_bytes(B, H, ND);
+    const size_t per2 = lstm_persist2_workspace_bytes(B, H, ND);
+    if (per2 > per) per = per2;
     return (step > per ? step : per) + 256;
 }
 
@@ -174,7 +185,9 @@ extern "C" int asr_lstm_fwd(float* gates, const float* whh, const float* bias2, 
     LstmP p{gates, whh, y, c, nullptr, bias2, B, T, H, ND};
     hipStream_t st = (hipStream_t)stream;
     if (workspace && persist_enabled() && ((uintptr_t)workspace & 255) == 0) {
-        int rc = lstm_fwd_persistent(gates, whh, bias2, y, c, B, T, H, ND, prec, workspace, workspace_bytes, st);
+        int rc = persist_mode() == 1 ? lstm_fwd_persistent2(gates, whh, bias2, y, c, B, T, H, ND, prec, workspace, workspace_bytes, st) : 1;
+        if (rc <= 0) return rc;
+        rc = lstm_fwd_persistent(gates, whh, bias2, y, c, B, T, H, ND, prec, workspace, workspace_bytes, st);
         if (rc <= 0) return rc;
     }
     dim3 grid(cdiv(H, 4), ND), block(64);
@@ -196,7 +209,9 @@ extern "C" int asr_lstm_bwd(float* gates, const float* whh, const float* dy, con
     ASR_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)gates & 15) == 0, ASR_E_ARG, "asr_lstm_bwd: unaligned");
     hipStream_t st = (hipStream_t)stream;
     if (persist_enabled()) {
-        int rc = lstm_bwd_persistent(gates, whh, dy, c, B, T, H, ND, prec, workspace, workspace_bytes, st);
+        int rc = persist_mode() == 1 ? lstm_bwd_persistent2(gates, whh, dy, c, B, T, H, ND, prec, workspace, workspace_bytes, st) : 1;
+        if (rc <= 0) return rc;
+        rc = lstm_bwd_persistent(gates, whh, dy, c, B, T, H, ND, prec, workspace, workspace_bytes, st);
         if (rc <= 0) return rc;
     }
     float* wt = (float*)((char*)workspace + 256);   // the first 256 bytes belong to the persistent path's status words

@@ -78,7 +78,8 @@ int asr_gemm(const float* A, const float* B, float* C, const float* bias,
  * persistent plan, a NULL workspace (forward) or ASR_LSTM_PERSIST=0 use one launch per time step.
  */
 size_t asr_lstm_workspace_bytes(int B, int H, int ND);
-/* 1 (default, or env ASR_LSTM_PERSIST) = persistent single-launch recurrence, 0 = one launch per step; returns the old value. */
+/* 1 (default, or env ASR_LSTM_PERSIST) = persistent single-launch recurrence, 0 = one launch per step,
+ * 2 = persistent but first-generation kernels only (A/B measurements); returns the old value. */
 int asr_lstm_set_persistent(int on);
 int asr_lstm_fwd(float* gates, const float* whh, const float* bias2, float* y, float* c,
                  int B, int T, int H, int ND, int prec,

@@ -16,12 +16,14 @@ def _cuda(*ts):
     return [t.cuda() for t in ts]
 
 
-@pytest.mark.parametrize('persistent', [1, 0])
+@pytest.mark.parametrize('persistent', [1, 2, 0])
 @pytest.mark.parametrize('prec', [0, 1])
-@pytest.mark.parametrize('B,T,H,ND', [(3, 11, 16, 2), (5, 7, 20, 1), (18, 9, 32, 2), (16, 33, 320, 2), (33, 21, 128, 2), (7, 40, 64, 1)])
+@pytest.mark.parametrize('B,T,H,ND', [(3, 11, 16, 2), (5, 7, 20, 1), (18, 9, 32, 2), (16, 33, 320, 2), (33, 21, 128, 2), (7, 40, 64, 1),
+                                      (1, 1, 16, 1), (5, 64, 48, 2), (16, 19, 512, 1), (11, 130, 320, 2)])
 def test_lstm_recurrence_fwd_bwd(B, T, H, ND, prec, persistent):
-    """persistent=1: single-launch recurrence with granule hand-offs (falls back by itself for H=20);
-    persistent=0: one launch per time step.  Both must match the oracle and leave the abort word at 0."""
+    """persistent=1: single-launch recurrence with granule hand-offs (second-generation kernels for bf16, B<=16,
+    H%16==0; first-generation otherwise; falls back by itself for H=20); persistent=2: first generation only;
+    persistent=0: one launch per time step.  All must match the oracle and leave the abort word at 0."""
     from src import hipabi as Hh
     old = Hh.lib().asr_lstm_set_persistent(persistent)
     try:

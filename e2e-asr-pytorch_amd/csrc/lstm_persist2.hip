@@ -16,9 +16,9 @@
 //    two fp32 partial sums per granule with the sequence number in their mantissa LSBs (2^-23 relative,
 //    far below the bf16 operand rounding).  Sequence = ((step >> 1) mod 3) + 1: consecutive occupants of a
 //    parity buffer differ, and the memset state 0 is never valid;
-//  * bulk traffic of a step (saved gates / c / y stores, prefetch of the operands two steps ahead) is issued
-//    right AFTER the first burst of polling loads: vmcnt retires in issue order, so anything issued before
-//    the poll would sit on the hand-off's critical path.
+//  * wave specialisation: four waves per workgroup do nothing but poll granules into LDS, four compute, publish
+//    and move the bulk traffic (saved gates / c / y stores, operand prefetch three steps ahead).  vmcnt retires
+//    in issue order, so a poll that shares a wave with bulk stores is not seen before those have completed.
 // Hand-off, bounded spins and the abort word are as in lstm_persist.hip (guide form R2).
 #include "common.h"
 
@@ -26,6 +26,20 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr int SPIN_LIMIT2 = 1 << 22;
+
+// Diagnostic build (make diag, -DASR_DIAG): wave 0 of workgroup (0,0) accumulates the wall time (100 MHz
+// s_memrealtime ticks) of each phase of a step into the status block (u64 words 2..9 of the workspace).
+#ifdef ASR_DIAG
+#define DIAG2_DECL unsigned long long dg_t = __builtin_amdgcn_s_memrealtime(), dg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DIAG2_MARK(k) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); dg_acc[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); }
+#define DIAG2_COUNT(k, v) { dg_acc[k] += (v); }
+#define DIAG2_DUMP(thr, word) { if (blockIdx.x == 0 && threadIdx.x == (thr)) { unsigned long long* o = (unsigned long long*)p.abort_flag + (word); for (int k = 0; k < 8; ++k) o[k] = dg_acc[k]; } }
+#else
+#define DIAG2_DECL
+#define DIAG2_MARK(k)
+#define DIAG2_COUNT(k, v) { (void)(v); }
+#define DIAG2_DUMP(thr, word)
+#endif
 
 struct P2 {
     float* gates;        // (B,T,ND,4H)
@@ -36,39 +50,78 @@ struct P2 {
     u64* xbuf;
     unsigned* abort_flag;
     int B, T, H, ND, P;
+    int allow_local;     // 1: use XCD-local hand-offs when all workgroups of a direction share an XCD
 };
 
 __device__ __forceinline__ u64 ld_gran(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_gran(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// `global_store_dwordx2 sc0`: reaches the XCD's L2 and keeps the line there (an `sc1` store drops it), so a
+// consumer on the SAME XCD is served by an L2 hit.  Only valid when producer and consumer share an XCD.
+__device__ __forceinline__ void st_gran_local(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <bool LOCAL> __device__ __forceinline__ void publish(u64* p, u64 v) { if (LOCAL) st_gran_local(p, v); else st_gran(p, v); }
+
+// Grid layout: workgroup i of the launch runs on XCD i % 8 under the dispatcher's round-robin placement, so the
+// P workgroups of direction d are the ones with i % 8 == d (the others exit at once) and share one L2.
+// Placement is never ASSUMED: every workgroup reads its XCC id, the ids are counted in one status word and only if all
+// P workgroups of the direction report the same XCD the hand-off uses L2-local stores; otherwise write-through.
+__device__ __forceinline__ bool xcd_consensus(u64* word, int P, int allow, unsigned* abort_flag) {
+    __shared__ int s_local;
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+        __hip_atomic_fetch_add(word, 1ull << (6 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int local = 0, spins = 0;
+        while (true) {
+            const u64 v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int sum = 0, mx = 0;
+            for (int k = 0; k < 8; ++k) { const int f = (int)((v >> (6 * k)) & 63u); sum += f; mx = max(mx, f); }
+            if (sum >= P) { local = (mx == P) && allow; break; }
+            if (++spins > SPIN_LIMIT2) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_local = local;
+        if ((blockIdx.x >> 3) == 0) reinterpret_cast<u64*>(abort_flag)[26 + (blockIdx.x & 7)] = (u64)local + 1;   // status: mode used (1 write-through, 2 XCD-local)
+    }
+    __syncthreads();
+    return s_local != 0;
+}
 __device__ __forceinline__ unsigned seq_of(int s) { return (unsigned)((s >> 1) % 3) + 1u; }
 
-// Fetches granules base[0], base[stride], ... (n <= CH of them) until all carry `want` under `mask`.
-// First round: the CH loads, then the caller's deferred memory traffic `io`, then the check.
-template <int CH, typename IO>
-__device__ __forceinline__ void gather_seq(const u64* base, long stride, int n, u64 mask, u64 want, u64 (&g)[CH],
-                                           unsigned* abort_flag, IO&& io) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) g[i] = ld_gran(base + (i < n ? i : 0) * stride);
-    __builtin_amdgcn_sched_barrier(0);
-    io();
-    __builtin_amdgcn_sched_barrier(0);
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// Fetches the 16-byte granule PAIRS base[0], base[stride], ... (n <= CH of them, base in u64 units and 16-byte aligned)
+// until both halves of each carry `want` under `mask`.  One `global_load_dwordx4 sc1` per pair: the bypass-load path of a
+// CU moves ~10 B/clk however it is cut up, and 8-byte loads reach only 0.54-0.70x the 16-byte rate, so the sweep of the
+// whole exchange vector - not the latency of one load - sets the length of a polling round.  All CH loads of a round are
+// issued back to back (entries >= n re-read entry 0 and are not checked).  Inline asm because the loads must be re-issued
+// every round; the gather waves have nothing else in their vector-memory queue, so `s_waitcnt vmcnt(0)` is exact.
+template <int CH>
+__device__ __forceinline__ int gather16(const u64* base, long stride, int n, u64 mask, u64 want, u64 (&lo)[CH], u64 (&hi)[CH],
+                                        unsigned* abort_flag) {
     int spins = 0;
     while (true) {
+        u32x4 v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const u64* a = base + (i < n ? i : 0) * stride;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) ok = ok && ((i >= n) || ((g[i] & mask) == want));
-        if (ok) return;
+        for (int i = 0; i < CH; ++i) {
+            lo[i] = (u64)v[i][0] | ((u64)v[i][1] << 32);
+            hi[i] = (u64)v[i][2] | ((u64)v[i][3] << 32);
+            ok = ok && ((i >= n) || (((lo[i] & mask) == want) && ((hi[i] & mask) == want)));
+        }
+        if (ok) return spins;
         ++spins;
         if ((spins & 63) == 0) {
-            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return spins;
             if (spins > SPIN_LIMIT2) {
                 __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+                return spins;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) g[i] = ld_gran(base + (i < n ? i : 0) * stride);
     }
 }
 
@@ -78,34 +131,86 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __built
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// Workgroup (p, dir): hidden units u0 = 16p .. 16p+15.  Wave g: gate g.  MFMA D[row = unit 4q+r][col = b = n]
-// = sum_k W_hh[g*H + u0 + row][k] * h_{t-1}[b][k].  Exchange buffer xbuf[parity][dir][b][H/4].
+// Workgroup (p, dir): hidden units u0 = 16p .. 16p+15, 8 waves in two roles:
+//   waves 0-3 (compute): wave g = gate g.  MFMA D[row = unit 4q+r][col = b = n] = sum_k W_hh[g*H + u0 + row][k] * h_{t-1}[b][k];
+//                        wave 0 also does the cell update and publishes h_t; all bulk global traffic lives here;
+//   waves 4-7 (gather):  poll the h_{t-1} granules of all workgroups into the LDS operand tile.  Their vector-memory
+//                        queue holds nothing but polls: vmcnt retires in issue order, so a poll issued behind bulk
+//                        stores / prefetches would not be seen before those have completed (measured: +1 us per step).
+// Exchange buffer xbuf[parity][dir][b][H/4].
+__host__ __device__ __forceinline__ long fwd_region(int B, int H) { return (long)B * (H >> 2); }   // granules per (parity, direction)
 constexpr u64 FWD_MASK = (1ull << 14) | (1ull << 30);
 __device__ __forceinline__ u64 fwd_want(unsigned seq) { return ((u64)(seq & 1u) << 14) | ((u64)(seq >> 1) << 30); }
 
 template <int NKS>
-__global__ __launch_bounds__(256) void lstm_fwd_p2(P2 p) {
+__global__ __launch_bounds__(512) void lstm_fwd_p2(P2 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.H, T = p.T, ND = p.ND, B = p.B;
-    const int d = blockIdx.y, u0 = blockIdx.x * 16;
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
-    const int n = lane & 15, q = lane >> 4;
+    if ((int)(blockIdx.x & 7) >= ND) return;
+    const int d = blockIdx.x & 7, u0 = (blockIdx.x >> 3) * 16;
+    const int tid = threadIdx.x;
     constexpr int LD = NKS * 32 + 8;                         // bf16 elements per operand-tile row (16-byte pad)
-    constexpr int CH = (NKS + 1) / 2;                        // granules per thread: 16 rows * (H/4) / 256
+    constexpr int CH = (NKS + 3) / 4;                        // 16-byte granule pairs per gather thread: 16 rows * (H/8) / 256
     __bf16* tiles = reinterpret_cast<__bf16*>(smem);         // [2][16][LD]  h_{t-1}, double buffered
     float* gbuf = reinterpret_cast<float*>(smem + 2 * 16 * LD * 2);   // [4][16][20] activated gates of this step
-    for (int i = tid; i < 2 * 16 * LD / 2; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+    for (int i = tid; i < 2 * 16 * LD / 2; i += 512) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+    const int HG = H >> 2, total = B * HG;
+    const long xregion = fwd_region(B, H);               // granules per (parity, direction)
+    const bool local = xcd_consensus(reinterpret_cast<u64*>(p.abort_flag) + 24 + d, p.P, p.allow_local, p.abort_flag);
 
+    if (tid >= 256) {
+        // ---- gather role ----
+        const int gt = tid - 256;
+        const int HG2 = HG >> 1, total2 = B * HG2;              // 16-byte pairs per row / in all
+        int slot_off[CH], cnt = 0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int idx = gt + 256 * i;
+            slot_off[i] = (idx < total2) ? (idx / HG2) * LD + (idx % HG2) * 8 : -1;
+            if (idx < total2) cnt = i + 1;
+        }
+        DIAG2_DECL
+        for (int s = 0; s < T; ++s) {
+            __bf16* tile = tiles + (s & 1) * 16 * LD;
+            if (s > 0 && cnt > 0) {
+                u64 glo[CH], ghi[CH];
+                const u64* src = p.xbuf + ((long)((s - 1) & 1) * ND + d) * xregion + 2 * gt;
+                const int sp = gather16<CH>(src, 512, cnt, FWD_MASK, fwd_want(seq_of(s - 1)), glo, ghi, p.abort_flag);
+                DIAG2_MARK(0)
+                DIAG2_COUNT(7, sp)
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    if (slot_off[i] >= 0) {
+                        u64* dst = reinterpret_cast<u64*>(tile + slot_off[i]);
+                        dst[0] = glo[i] & ~FWD_MASK;
+                        dst[1] = ghi[i] & ~FWD_MASK;
+                    }
+            }
+            DIAG2_MARK(1)
+            __syncthreads();
+            DIAG2_MARK(2)
+            __syncthreads();
+            DIAG2_MARK(3)
+        }
+        DIAG2_DUMP(256, 10)
+        return;
+    }
+
+    // ---- compute role ----
+    const int lane = tid & 63, g = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
     bf16x8 w[NKS];
     {
         const float* wrow = p.whh + ((long)d * 4 * H + (long)g * H + u0 + n) * H;
+        float wf[NKS][8];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = ks * 32 + 8 * q + e;
-                w[ks][e] = (__bf16)((k < H) ? wrow[k] : 0.f);
-            }
+            for (int e = 0; e < 8; ++e) wf[ks][e] = wrow[min(ks * 32 + 8 * q + e, H - 1)];      // all loads in flight
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[ks][e] = (__bf16)((ks * 32 + 8 * q + e < H) ? wf[ks][e] : 0.f);
     }
     float bias[4];
 #pragma unroll
@@ -114,59 +219,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_p2(P2 p) {
     const bool bok = n < B;
     const int bc = bok ? n : 0;
     const long g_ts = (long)ND * 4 * H, c_ts = (long)ND * H;
-    const float* xg_base = p.gates + ((long)bc * T * ND + d) * 4 * H + (long)g * H + u0 + 4 * q;
     float* gs_base = p.gates + ((long)bc * T * ND + d) * 4 * H + (long)g * H + u0 + 4 * q;
     const long cy_off = ((long)bc * T * ND + d) * H + u0 + 4 * q;
     auto tix = [&](int s_) { return (d == 0) ? s_ : T - 1 - s_; };
     auto ldx = [&](int s_) -> float4 {
-        if (s_ < T && bok) return *reinterpret_cast<const float4*>(xg_base + (long)tix(s_) * g_ts);
+#ifndef ASR_NOIO
+        if (s_ < T && bok) return *reinterpret_cast<const float4*>(gs_base + (long)tix(s_) * g_ts);
+#endif
         return make_float4(0.f, 0.f, 0.f, 0.f);
     };
+    float4 xgA = ldx(0), xgB = ldx(1), xgC = ldx(2);
+    float4 cst = make_float4(0.f, 0.f, 0.f, 0.f);
+    DIAG2_DECL
 
-    const int HG = H >> 2, total = B * HG;
-    const long xstride = (long)ND * B * HG;
-    int slot_off[CH], cnt = 0;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int idx = tid + 256 * i;
-        slot_off[i] = (idx < total) ? (idx / HG) * LD + (idx % HG) * 4 : -1;
-        if (idx < total) cnt = i + 1;
-    }
-    float4 xgA = ldx(0), xgB = ldx(1), xgC = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 o_gate = xgC, o_c = xgC, o_h = xgC, cst = xgC;
-    __syncthreads();
-
-    for (int s = 0; s <= T; ++s) {
-        // deferred bulk traffic: outputs of step s-1, operands of step s+2
-        auto io = [&]() {
-            if (s > 0 && bok) {
-                const long tp = tix(s - 1);
-                *reinterpret_cast<float4*>(gs_base + tp * g_ts) = o_gate;
-                if (g == 0) {
-                    *reinterpret_cast<float4*>(p.c + cy_off + tp * c_ts) = o_c;
-                    *reinterpret_cast<float4*>(p.y + cy_off + tp * c_ts) = o_h;
-                }
-            }
-            xgC = ldx(s + 2);
-        };
-        if (s == T) { io(); break; }
-        __bf16* tile = tiles + (s & 1) * 16 * LD;
-        if (s > 0 && cnt > 0) {
-            u64 gr[CH];
-            const u64* src = p.xbuf + (long)((s - 1) & 1) * xstride + (long)d * B * HG + tid;
-            gather_seq<CH>(src, 256, cnt, FWD_MASK, fwd_want(seq_of(s - 1)), gr, p.abort_flag, io);
-#pragma unroll
-            for (int i = 0; i < CH; ++i)
-                if (slot_off[i] >= 0) *reinterpret_cast<u64*>(tile + slot_off[i]) = gr[i] & ~FWD_MASK;
-        } else {
-            io();
-        }
-        __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const long t = tix(s);
+        const __bf16* tile = tiles + (s & 1) * 16 * LD;
+        DIAG2_MARK(7)
+        __syncthreads();                         // h_{t-1} tile complete
+        DIAG2_MARK(0)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
+            bf16x8 hb[NKS];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                acc = mma16(w[ks], *reinterpret_cast<const bf16x8*>(tile + n * LD + ks * 32 + 8 * q), acc);
+            for (int ks = 0; ks < NKS; ++ks) hb[ks] = *reinterpret_cast<const bf16x8*>(tile + n * LD + ks * 32 + 8 * q);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) acc = mma16(w[ks], hb[ks], acc);
         }
         float a[4];
         const float xr[4] = {xgA.x, xgA.y, xgA.z, xgA.w};
@@ -175,9 +253,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_p2(P2 p) {
             const float pre = acc[r] + xr[r] + bias[r];
             a[r] = (g == 2) ? fast_tanh(pre) : fast_sigmoid(pre);
         }
-        o_gate = make_float4(a[0], a[1], a[2], a[3]);
+        const float4 o_gate = make_float4(a[0], a[1], a[2], a[3]);
         *reinterpret_cast<float4*>(gbuf + (g * 16 + n) * 20 + 4 * q) = o_gate;
-        __syncthreads();
+        DIAG2_MARK(1)
+        __syncthreads();                         // the four gates of this step are in LDS
+        DIAG2_MARK(2)
         if (g == 0) {
             const float4 gi = *reinterpret_cast<const float4*>(gbuf + (0 * 16 + n) * 20 + 4 * q);
             const float4 gf = *reinterpret_cast<const float4*>(gbuf + (1 * 16 + n) * 20 + 4 * q);
@@ -185,20 +265,33 @@ __global__ __launch_bounds__(256) void lstm_fwd_p2(P2 p) {
             const float4 go = *reinterpret_cast<const float4*>(gbuf + (3 * 16 + n) * 20 + 4 * q);
             cst.x = gf.x * cst.x + gi.x * gg.x; cst.y = gf.y * cst.y + gi.y * gg.y;
             cst.z = gf.z * cst.z + gi.z * gg.z; cst.w = gf.w * cst.w + gi.w * gg.w;
-            o_c = cst;
-            o_h = make_float4(go.x * fast_tanh(cst.x), go.y * fast_tanh(cst.y), go.z * fast_tanh(cst.z), go.w * fast_tanh(cst.w));
+            const float4 o_h = make_float4(go.x * fast_tanh(cst.x), go.y * fast_tanh(cst.y), go.z * fast_tanh(cst.z), go.w * fast_tanh(cst.w));
             if (s + 1 < T && bok) {
                 // bit 14 of a bf16 is clear for every |x| < 2; clearing it (only NaN/Inf are affected, and those
-                // still reach the loss through y) keeps the sequence bits intact in all cases
+                // still reach the loss through y) keeps the sequence bits (bits 14 and 30 of the granule) intact
                 const u64 b0 = f2bf_bits(o_h.x) & 0xBFFFu, b1 = f2bf_bits(o_h.y) & 0xBFFFu;
                 const u64 b2 = f2bf_bits(o_h.z), b3 = f2bf_bits(o_h.w);
                 const u64 v = b0 | (b1 << 16) | (b2 << 32) | (b3 << 48);
-                // sequence bits live in elements 0 and 1 (bits 14 and 30)
-                st_gran(p.xbuf + (long)(s & 1) * xstride + ((long)d * B + n) * HG + (u0 >> 2) + q, v | fwd_want(seq_of(s)));
+                u64* dst = p.xbuf + ((long)(s & 1) * ND + d) * xregion + n * HG + (u0 >> 2) + q;
+                if (local) publish<true>(dst, v | fwd_want(seq_of(s)));
+                else publish<false>(dst, v | fwd_want(seq_of(s)));
             }
+#ifndef ASR_NOIO
+            if (bok) {
+                *reinterpret_cast<float4*>(p.c + cy_off + t * c_ts) = cst;
+                *reinterpret_cast<float4*>(p.y + cy_off + t * c_ts) = o_h;
+            }
+#endif
         }
-        xgA = xgB; xgB = xgC;
+        DIAG2_MARK(3)
+        // saved activated gate (for BPTT) and the input-projection operand three steps ahead
+#ifndef ASR_NOIO
+        if (bok) *reinterpret_cast<float4*>(gs_base + t * g_ts) = o_gate;
+#endif
+        xgA = xgB; xgB = xgC; xgC = ldx(s + 3);
+        DIAG2_MARK(4)
     }
+    DIAG2_DUMP(0, 2)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,35 +300,84 @@ __global__ __launch_bounds__(256) void lstm_fwd_p2(P2 p) {
 // Workgroup (me, dir) owns units j0 = 16*me .. +15: it turns their dh into the four gate-pre-activation
 // gradients (K = 64 reduction index nl = g*16 + jl) and multiplies by its W_hh rows: a PARTIAL dh_{t-1}[b, all H].
 // MFMA D[row = k' unit 4q+r of output tile][col = b = n].  Output tile tcol (16 units) belongs to workgroup tcol.
+// Waves 0-3: cell backward, MFMA, publish, bulk traffic.  Waves 4-7: poll and sum the producers' partials
+// (wave 4+k sums producers [k*NTO, (k+1)*NTO)).
 // Exchange buffer xbuf[parity][dir][consumer][producer][b][8 pairs of fp32].
 constexpr u64 BWD_MASK = 1ull | (1ull << 32);
 __device__ __forceinline__ u64 bwd_want(unsigned seq) { return (u64)(seq & 1u) | ((u64)(seq >> 1) << 32); }
 
 template <int NTO>
-__global__ __launch_bounds__(256) void lstm_bwd_p2(P2 p) {
+__global__ __launch_bounds__(512) void lstm_bwd_p2(P2 p) {
     __shared__ __attribute__((aligned(16))) __bf16 tile[16 * 72];     // [b][64 + 8] dgates of this slice
-    __shared__ __attribute__((aligned(16))) float s_part[2 * 256];   // [producer half][b][16]
+    __shared__ __attribute__((aligned(16))) float s_part[4 * 256];   // [producer group][b][16]
     const int H = p.H, T = p.T, ND = p.ND, B = p.B, P = p.P;
-    const int d = blockIdx.y, me = blockIdx.x, j0 = me * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, q = lane >> 4;
+    if ((int)(blockIdx.x & 7) >= ND) return;
+    const int d = blockIdx.x & 7, me = blockIdx.x >> 3, j0 = me * 16;
+    const int tid = threadIdx.x;
     constexpr int LD = 72;
-    for (int i = tid; i < 16 * LD / 2; i += 256) reinterpret_cast<unsigned*>(tile)[i] = 0u;
+    for (int i = tid; i < 16 * LD / 2; i += 512) reinterpret_cast<unsigned*>(tile)[i] = 0u;
+    const long per_par = (long)ND * P * P * B * 8;
+    const bool local = xcd_consensus(reinterpret_cast<u64*>(p.abort_flag) + 24 + d, P, p.allow_local, p.abort_flag);
 
+    if (tid >= 256) {
+        // ---- gather role: (row gb, unit quad g4) x producer group gq (NTO = ceil(P/4) producers each) ----
+        const int gt = tid - 256;
+        const int gslot = gt & 63, gb = gslot >> 2, g4 = gslot & 3, gq = gt >> 6;
+        const int pp_lo = gq * NTO, cntp = max(0, min(P - pp_lo, NTO));
+        DIAG2_DECL
+        for (int s = 0; s < T; ++s) {
+            if (s > 0) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                if (gb < B && cntp > 0) {
+                    const u64* src = p.xbuf + (long)((s - 1) & 1) * per_par + (((long)d * P + me) * P + pp_lo) * B * 8 + gb * 8 + 2 * g4;
+                    u64 glo[NTO], ghi[NTO];
+                    gather16<NTO>(src, (long)B * 8, cntp, BWD_MASK, bwd_want(seq_of(s - 1)), glo, ghi, p.abort_flag);
+#pragma unroll
+                    for (int i = 0; i < NTO; ++i)
+                        if (i < cntp) {
+                            a0 += __uint_as_float((unsigned)glo[i] & ~1u);
+                            a1 += __uint_as_float((unsigned)(glo[i] >> 32) & ~1u);
+                            a2 += __uint_as_float((unsigned)ghi[i] & ~1u);
+                            a3 += __uint_as_float((unsigned)(ghi[i] >> 32) & ~1u);
+                        }
+                }
+                DIAG2_MARK(0)
+                *reinterpret_cast<float4*>(s_part + gq * 256 + gb * 16 + 4 * g4) = make_float4(a0, a1, a2, a3);
+            }
+            DIAG2_MARK(1)
+            __syncthreads();
+            DIAG2_MARK(2)
+            __syncthreads();
+            DIAG2_MARK(3)
+        }
+        DIAG2_DUMP(256, 10)
+        return;
+    }
+
+    // ---- compute role ----
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
     // resident weights, A operand: row = output unit kp = 16*tcol + n, k = nl = 32*ks + 8q + e
     bf16x8 w[NTO][2];
+    {
+        float wf[NTO][2][8];
 #pragma unroll
-    for (int ot = 0; ot < NTO; ++ot) {
-        const int tcol = wave + 4 * ot;
+        for (int ot = 0; ot < NTO; ++ot) {
+            const int tcol = min(wave + 4 * ot, P - 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int nl = ks * 32 + 8 * q + e;
-                float v = 0.f;
-                if (tcol < P) v = p.whh[((long)d * 4 * H + (long)(nl >> 4) * H + j0 + (nl & 15)) * H + tcol * 16 + n];
-                w[ot][ks][e] = (__bf16)v;
-            }
+                for (int e = 0; e < 8; ++e) {
+                    const int nl = ks * 32 + 8 * q + e;
+                    wf[ot][ks][e] = p.whh[((long)d * 4 * H + (long)(nl >> 4) * H + j0 + (nl & 15)) * H + tcol * 16 + n];
+                }
+        }
+#pragma unroll
+        for (int ot = 0; ot < NTO; ++ot)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[ot][ks][e] = (__bf16)wf[ot][ks][e];
     }
 
     // element owned by this thread in the cell backward: (row eb, unit j0 + ej)
@@ -257,7 +399,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_p2(P2 p) {
             r.dy = p.y[cy_e + (long)t * c_ts];
             r.gi = gp[0]; r.gf = gp[H]; r.gg = gp[2 * (long)H]; r.go = gp[3 * (long)H];
             r.c = p.c[cy_e + (long)t * c_ts];
-            r.cp = has_cp ? p.c[cy_e + (long)tp * c_ts] : 0.f;
+            r.cp = p.c[cy_e + (long)(has_cp ? tp : t) * c_ts];
+            if (!has_cp) r.cp = 0.f;
         }
         return r;
     };
@@ -275,60 +418,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_p2(P2 p) {
         return k;
     };
 
-    // gather role: (row gb, unit pair gp) x producer half gh
-    const int gslot = tid & 127, gb = gslot >> 3, gpr = gslot & 7, gh = tid >> 7;
-    const int PH = (P + 1) >> 1;
-    const int pp_lo = gh * PH, pp_hi = min(P, pp_lo + PH);
-    const long per_par = (long)ND * P * P * B * 8;
-
     Coef coef = make_coef(load_raw(0));
     Raw rawB = load_raw(1);
-    Raw rawC = rawB;
+    Raw rawC = load_raw(2);
     float carry = 0.f;
-    float dgv[4] = {0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    DIAG2_DECL
 
-    for (int s = 0; s <= T; ++s) {
-        auto io = [&]() {
-            if (s > 0 && eok) {
-                float* gp = ge + (long)tix(s - 1) * g_ts;
-                gp[0] = dgv[0]; gp[H] = dgv[1]; gp[2 * (long)H] = dgv[2]; gp[3 * (long)H] = dgv[3];
-            }
-            rawC = load_raw(s + 2);
-        };
-        if (s == T) { io(); break; }
-        // 1. recurrent dh of the owned slice: sum of the producers' partials (sequence of step s-1)
-        if (s > 0) {
-            float a0 = 0.f, a1 = 0.f;
-            if (gb < B && pp_lo < pp_hi) {
-                const u64* src = p.xbuf + (long)((s - 1) & 1) * per_par + (((long)d * P + me) * P) * B * 8 + gb * 8 + gpr;
-                const u64 want = bwd_want(seq_of(s - 1));
-                bool first = true;
-                for (int pp0 = pp_lo; pp0 < pp_hi; pp0 += 10) {
-                    u64 gr[10];
-                    const int c = min(10, pp_hi - pp0);
-                    if (first) gather_seq<10>(src + (long)pp0 * B * 8, (long)B * 8, c, BWD_MASK, want, gr, p.abort_flag, io);
-                    else gather_seq<10>(src + (long)pp0 * B * 8, (long)B * 8, c, BWD_MASK, want, gr, p.abort_flag, []() {});
-                    first = false;
-#pragma unroll
-                    for (int i = 0; i < 10; ++i)
-                        if (i < c) {
-                            a0 += __uint_as_float((unsigned)gr[i] & ~1u);
-                            a1 += __uint_as_float((unsigned)(gr[i] >> 32) & ~1u);
-                        }
-                }
-            } else {
-                io();
-            }
-            *reinterpret_cast<float2*>(s_part + gh * 256 + gb * 16 + 2 * gpr) = make_float2(a0, a1);
-            __syncthreads();
-        } else {
-            io();
-        }
-        // 2. cell backward of the owned element -> bf16 operand tile
+    for (int s = 0; s < T; ++s) {
+        DIAG2_MARK(7)
+        __syncthreads();                         // recurrent partial sums of step s are in s_part
+        DIAG2_MARK(0)
+        // cell backward of the owned element -> bf16 operand tile
+        float dgv[4];
         {
             float dh = coef.dy;
-            if (s > 0) dh += s_part[tid] + s_part[256 + tid];
+            if (s > 0) dh += (s_part[tid] + s_part[256 + tid]) + (s_part[512 + tid] + s_part[768 + tid]);
             const float dc = dh * coef.c1 + carry;
             dgv[0] = dc * coef.c2; dgv[1] = dc * coef.c3; dgv[2] = dc * coef.c4; dgv[3] = dh * coef.c5;
             carry = dc * coef.f;
@@ -339,44 +443,61 @@ __global__ __launch_bounds__(256) void lstm_bwd_p2(P2 p) {
                 tile[eb * LD + 48 + ej] = (__bf16)dgv[3];
             }
         }
+        DIAG2_MARK(1)
         __syncthreads();
-        // 3. partial dh_{prev}[b, k'] for every k', handed to the owner of k'
+        DIAG2_MARK(2)
+        // partial dh_{prev}[b, k'] for every k', handed to the owner of k'
         if (s + 1 < T) {
             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(tile + n * LD + 8 * q);
             const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(tile + n * LD + 32 + 8 * q);
             u64* dst = p.xbuf + (long)(s & 1) * per_par + (long)d * P * P * B * 8;
             const u64 want = bwd_want(seq_of(s));
+            f32x4 acc[NTO];
+#pragma unroll
+            for (int ot = 0; ot < NTO; ++ot) {
+                acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[ot] = mma16(w[ot][0], b0, acc[ot]);
+                acc[ot] = mma16(w[ot][1], b1, acc[ot]);
+            }
 #pragma unroll
             for (int ot = 0; ot < NTO; ++ot) {
                 const int tcol = wave + 4 * ot;
-                if (tcol < P) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mma16(w[ot][0], b0, acc);
-                    acc = mma16(w[ot][1], b1, acc);
-                    if (n < B) {
-                        u64* o = dst + (((long)tcol * P + me) * B + n) * 8 + 2 * q;
-                        const u64 v0 = (u64)(__float_as_uint(acc[0]) & ~1u) | ((u64)(__float_as_uint(acc[1]) & ~1u) << 32);
-                        const u64 v1 = (u64)(__float_as_uint(acc[2]) & ~1u) | ((u64)(__float_as_uint(acc[3]) & ~1u) << 32);
-                        st_gran(o, v0 | want);
-                        st_gran(o + 1, v1 | want);
-                    }
+                if (tcol < P && n < B) {
+                    u64* o = dst + (((long)tcol * P + me) * B + n) * 8 + 2 * q;
+                    const u64 v0 = (u64)(__float_as_uint(acc[ot][0]) & ~1u) | ((u64)(__float_as_uint(acc[ot][1]) & ~1u) << 32);
+                    const u64 v1 = (u64)(__float_as_uint(acc[ot][2]) & ~1u) | ((u64)(__float_as_uint(acc[ot][3]) & ~1u) << 32);
+                    if (local) { publish<true>(o, v0 | want); publish<true>(o + 1, v1 | want); }
+                    else { publish<false>(o, v0 | want); publish<false>(o + 1, v1 | want); }
                 }
             }
         }
-        // 4. coefficients of the next step from the operands requested one step ago
+        DIAG2_MARK(3)
+        // gradients wrt the gate pre-activations replace the saved gates; operands three steps ahead; next coefficients
+        if (eok) {
+            float* gp = ge + (long)tix(s) * g_ts;
+            gp[0] = dgv[0]; gp[H] = dgv[1]; gp[2 * (long)H] = dgv[2]; gp[3 * (long)H] = dgv[3];
+        }
         coef = make_coef(rawB);
         rawB = rawC;
+        rawC = load_raw(s + 3);
+        DIAG2_MARK(4)
     }
+    DIAG2_DUMP(0, 2)
 }
 
 template <typename KernelT>
 int launch_p2(KernelT kernel, const P2& p, size_t lds, hipStream_t st, const char* name) {
-    hipLaunchKernelGGL(kernel, dim3(p.P, p.ND), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kernel, dim3(8 * p.P), dim3(512), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { asr_set_error("%s: launch failed: %s", name, hipGetErrorString(e)); return ASR_E_LAUNCH; }
     return ASR_OK;
 }
 
+int allow_local() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on;
+}
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -384,7 +505,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 size_t lstm_persist2_workspace_bytes(int B, int H, int ND) {
     if (H % 16 != 0 || B > 16 || H > 512) return 0;
     const size_t P = H / 16;
-    const size_t fwd = 2 * (size_t)ND * B * (H / 4) * sizeof(u64);
+    const size_t fwd = 2 * (size_t)ND * fwd_region(B, H) * sizeof(u64);
     const size_t bwd = 2 * (size_t)ND * P * P * B * 8 * sizeof(u64);
     return 256 + (fwd > bwd ? fwd : bwd);
 }
@@ -399,10 +520,10 @@ int lstm_fwd_persistent2(float* gates, const float* whh, const float* bias2, flo
                          int B, int T, int H, int ND, int prec, void* ws, size_t ws_bytes, hipStream_t st) {
     if (prec != ASR_BF16 || B > 16 || H % 16 != 0 || H > 512 || !ws) return 1;
     if (!aligned16(gates) || !aligned16(y) || !aligned16(c)) return 1;
-    const size_t need = 256 + 2 * (size_t)ND * B * (H / 4) * sizeof(u64);
+    const size_t need = 256 + 2 * (size_t)ND * fwd_region(B, H) * sizeof(u64);
     if (ws_bytes < need) return 1;
     hipMemsetAsync(ws, 0, need, st);
-    P2 p{gates, whh, bias2, y, c, (u64*)((char*)ws + 256), (unsigned*)ws, B, T, H, ND, H / 16};
+    P2 p{gates, whh, bias2, y, c, (u64*)((char*)ws + 256), (unsigned*)ws, B, T, H, ND, H / 16, allow_local()};
     const int nks = (H + 31) / 32;
     FWD2_CASE(1) FWD2_CASE(2) FWD2_CASE(4) FWD2_CASE(6) FWD2_CASE(8) FWD2_CASE(10) FWD2_CASE(12) FWD2_CASE(16)
     return 1;
@@ -416,7 +537,7 @@ int lstm_bwd_persistent2(float* gates, const float* whh, const float* dy, const 
     if (ws_bytes < need) return 1;
     hipMemsetAsync(ws, 0, need, st);
     P2 p{gates, whh, nullptr, const_cast<float*>(dy), const_cast<float*>(c), (u64*)((char*)ws + 256), (unsigned*)ws,
-         B, T, H, ND, (int)P};
+         B, T, H, ND, (int)P, allow_local()};
     const int nto = ((int)P + 3) / 4;
     BWD2_CASE(1) BWD2_CASE(2) BWD2_CASE(3) BWD2_CASE(4) BWD2_CASE(5) BWD2_CASE(6) BWD2_CASE(8)
     return 1;

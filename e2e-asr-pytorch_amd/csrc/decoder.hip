@@ -18,8 +18,8 @@ namespace {
 constexpr int TT = 16;   // encoder frames per workgroup in the energy kernels (4 waves x TPW frames)
 constexpr int TPW = TT / 4;
 
-// tanh via one v_exp: 1 - 2/(1+e^{2x}); absolute error ~1e-7 (the energy kernels evaluate ~6 M of these per step)
-__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+// tanh via one v_exp and one v_rcp: 1 - 2/(1+e^{2x}); absolute error ~2e-7 (the energy kernels evaluate ~6 M of these per step)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 struct DecP {
     asr_dec_dims_t d;
@@ -117,44 +117,111 @@ __device__ __forceinline__ void conv_tile(const DecP& p, int b, int t, int tau0,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: energies.  grid (ceil(T'/TT), B), 4 waves x 16 frames, lanes over the attention dimension.
+// K2: energies.  grid (ceil(T'/TE), B), TE = 8 waves x TPW frames; wave w owns frames w*TPW.., lanes sweep the
+// attention dimension.  TPW is chosen by the host so that the whole batch is ONE round of workgroups (<= 1 per CU):
+// the kernel is a chain of dependent round trips (window -> conv -> keys -> reduce), not bandwidth, so a second
+// round of workgroups doubles its time.  Every global operand of the sweep is requested before the location
+// convolution is computed; the convolution itself is spread over all 512 threads (tap ranges x 4-frame groups).
+// conv (B,L,Kn,T') is kept for the backward pass when state.conv != NULL.
 // ------------------------------------------------------------------------------------------------
-template <int KNMAX>
-__global__ __launch_bounds__(256) void att_energy_kernel(DecP p, int t) {
+template <int KNMAX, int TPW>
+__global__ __launch_bounds__(512) void att_energy_kernel(DecP p, int t) {
+    constexpr int TE = 8 * TPW, NA = 5;                 // NA: attention columns per lane held in flight
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const asr_dec_dims_t& d = p.d;
-    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
-    float* s_pa = smem_f;
-    float* s_wc = s_pa + (TT + 2 * d.Ks);
-    float* s_conv = s_wc + d.Kn * (2 * d.Ks + 1);
-    conv_tile(p, b, t, tau0, s_pa, s_wc, s_conv);
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int len = (int)p.enc_len[b];
+    const int b = blockIdx.y, tau0 = blockIdx.x * TE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int taps = 2 * d.Ks + 1, win = TE + 2 * d.Ks;
+    const int len = min((int)p.enc_len[b], d.Tp);
+    float* s_pa = smem_f;                               // [win]            previous attention window
+    float* s_wc = s_pa + ((win + 3) & ~3);              // [Kn*taps]        location filters
+    float* s_conv = s_wc + ((d.Kn * taps + 3) & ~3);    // [Kn*TE]          conv output of the tile
+    float* s_wp = s_conv + d.Kn * TE;                   // [Kn][A]          W_proj transposed
+    float* s_part = s_wp + ((d.Kn * d.A + 3) & ~3);     // [parts][Kn*TE]   partial conv sums
+    // ---- stage 0: every global read that does not depend on the convolution
+    {
+        const float* prev = (t > 0) ? p.s.att + ((long)b * d.L + (t - 1)) * d.Tp : nullptr;
+        const float uni = 1.f / (float)max(len, 1);
+        for (int i = tid; i < win; i += 512) {
+            const int tau = tau0 + i - d.Ks;
+            float v = 0.f;
+            if (tau >= 0 && tau < d.Tp) v = prev ? prev[tau] : (tau < len ? uni : 0.f);
+            s_pa[i] = v;
+        }
+        for (int i = tid; i < d.Kn * taps; i += 512) s_wc[i] = p.w.Wconv[i];
+        for (int i = tid; i < d.Kn * d.A; i += 512) { const int a = i / d.Kn, k = i - a * d.Kn; s_wp[k * d.A + a] = p.w.Wproj[i]; }
+    }
     const float* qrow = p.s.q + ((long)b * d.L + t) * d.A;
+    const int tmax = max(len - 1, 0);
+    float kv[NA][TPW], qa[NA], wga[NA];
+    auto load_cols = [&](int a0) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            const int a = min(a0 + 64 * c + lane, d.A - 1);
+            qa[c] = qrow[a]; wga[c] = p.w.wg[a];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) kv[c][i] = p.s.key[((long)b * d.Tp + min(tau0 + wave * TPW + i, tmax)) * d.A + a];
+        }
+    };
+    load_cols(0);
+    __syncthreads();
+    // ---- stage 1: conv[k][i] = sum_j Wconv[k][j] * pa[i + j];  item = (tap range, k, group of 4 frames)
+    {
+        const int ngrp = TE / 4, nout = d.Kn * ngrp;
+        const int parts = max(1, min(8, 512 / nout));
+        const int tp = (taps + parts - 1) / parts;
+        for (int it = tid; it < parts * nout; it += 512) {
+            const int pz = it / nout, o = it - pz * nout, k = o / ngrp, ig = o - k * ngrp;
+            const int j0 = pz * tp, j1 = min(taps, j0 + tp);
+            const float* wk = s_wc + k * taps;
+            const float* pa = s_pa + 4 * ig;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float p0 = pa[j0], p1 = pa[j0 + 1], p2 = pa[j0 + 2];
+            for (int j = j0; j < j1; ++j) {
+                const float w = wk[j], p3 = pa[j + 3];
+                a0 += w * p0; a1 += w * p1; a2 += w * p2; a3 += w * p3;
+                p0 = p1; p1 = p2; p2 = p3;
+            }
+            float* o4 = s_part + (long)pz * d.Kn * TE + k * TE + 4 * ig;
+            o4[0] = a0; o4[1] = a1; o4[2] = a2; o4[3] = a3;
+        }
+        __syncthreads();
+        for (int o = tid; o < d.Kn * TE; o += 512) {
+            float v = 0.f;
+            for (int pz = 0; pz < parts; ++pz) v += s_part[(long)pz * d.Kn * TE + o];
+            s_conv[o] = v;
+            const int k = o / TE, tau = tau0 + (o - k * TE);
+            if (p.s.conv && tau < d.Tp) p.s.conv[(((long)b * d.L + t) * d.Kn + k) * d.Tp + tau] = v;
+        }
+        __syncthreads();
+    }
+    // ---- stage 2: sweep.  The wave's conv values are the same for every lane: keep them in registers.
+    float cv[KNMAX][TPW];
+#pragma unroll
+    for (int k = 0; k < KNMAX; ++k)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) cv[k][i] = (k < d.Kn) ? s_conv[k * TE + wave * TPW + i] : 0.f;
     float e[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) e[i] = 0.f;
-    const int tmax = max(min(len, d.Tp) - 1, 0);
-    for (int a = lane; a < d.A; a += 64) {
-        float wp[KNMAX];
+    for (int a0 = 0; a0 < d.A; a0 += 64 * NA) {
+        if (a0 > 0) load_cols(a0);
 #pragma unroll
-        for (int k = 0; k < KNMAX; ++k) wp[k] = (k < d.Kn) ? p.w.Wproj[(long)a * d.Kn + k] : 0.f;
-        const float qa = qrow[a], wga = p.w.wg[a];
-        float kv[TPW];
+        for (int c = 0; c < NA; ++c) {
+            const int a = a0 + 64 * c + lane;
+            const bool aok = a < d.A;
+            const int ac = aok ? a : d.A - 1;
+            float wp[KNMAX];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {   // all key loads of this column in flight together
-            const int tau = min(tau0 + wave * TPW + i, tmax);
-            kv[i] = p.s.key[((long)b * d.Tp + tau) * d.A + a];
-        }
+            for (int k = 0; k < KNMAX; ++k) wp[k] = (k < d.Kn) ? s_wp[k * d.A + ac] : 0.f;
+            const float wg_ = aok ? wga[c] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int ti = wave * TPW + i;
-            float lp = 0.f;
+            for (int i = 0; i < TPW; ++i) {
+                float lp = 0.f;
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
-            const float u = tanh_fast(kv[i] + qa + tanh_fast(lp));
-            e[i] += (tau0 + ti < len) ? wga * u : 0.f;
+                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * cv[k][i];
+                e[i] += wg_ * tanh_fast(kv[c][i] + qa[c] + tanh_fast(lp));
+            }
         }
     }
 #pragma unroll
@@ -363,17 +430,14 @@ struct DecB {
     asr_dec_grads_t g;
     float* dhs;        // (B,L,NL,Dd)   gradient wrt every h (accumulated in place)
     float* dxin;       // (B,L,Dd+E)
-    float* dq;         // (B,L,A)       in: sum_tau du (atomics);  out: gradient wrt the query pre-activation
+    float* dq;         // (B,L,A)       gradient wrt the query pre-activation (per-tile partials added atomically)
     float* dkey;       // (B,T',A)
-    float* dattn;      // (B,T')        scratch of the current step
     float* datt_next;  // (B,T')        gradient flowing into attn_t from step t+1's location conv
-    float* dconv;      // (B,Kn,T')
-    float* dqpart;     // (B,ntiles,A)  per-workgroup partial sums of du over the tile's frames
     float* dcf;        // (NL,B,Dd)
     float* wcatT[ASR_MAX_DEC_LAYERS];  // ((Kx+Dd) x 4Dd) transposed [W_ih ; W_hh]
     float* wqT;        // (Q x A)
-    float* slots;      // (B*ntiles, SLOT) per-workgroup partial sums of d w_g, d W_proj, d b_g, d W_conv
-    int ntiles, slot;
+    float* slots;      // (B*nte, slot) per-workgroup partial sums of d w_g, d W_proj ([k][a]), d b_g
+    int nte, slot;     // energy-backward tiles per utterance, floats per slot
 };
 
 // cell backward, elementwise part: dgates (in place over the activated gates) and the dc*f carry
@@ -439,270 +503,302 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_mm_kernel(DecB p, int t, int
     }
 }
 
-// B2a: dattn[b,tau] = dctx[b] . enc[b,tau] + datt_next[b,tau]
-__global__ __launch_bounds__(256) void att_bwd_dattn_kernel(DecB p, int t, int last) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];  // dctx [E]
-    const asr_dec_dims_t& d = p.f.d;
-    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int len = min((int)p.f.enc_len[b], d.Tp);
-    const float* dctx = p.dxin + ((long)b * d.L + t) * (d.Dd + d.E) + d.Dd;
-    for (int i = threadIdx.x; i < d.E; i += 256) smem_f[i] = dctx[i];
-    __syncthreads();
-    const int tmax = max(len - 1, 0);
-    for (int i0 = 0; i0 < TPW; i0 += 4) {
-        const int tb = tau0 + wave * TPW + i0;
-        if (tb >= d.Tp) break;
-        const float* r0 = p.f.enc + ((long)b * d.Tp + min(tb, tmax)) * d.E;
-        const float* r1 = p.f.enc + ((long)b * d.Tp + min(tb + 1, tmax)) * d.E;
-        const float* r2 = p.f.enc + ((long)b * d.Tp + min(tb + 2, tmax)) * d.E;
-        const float* r3 = p.f.enc + ((long)b * d.Tp + min(tb + 3, tmax)) * d.E;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 4
-        for (int e = lane; e < d.E; e += 64) {
-            const float c = smem_f[e];
-            a0 += c * r0[e]; a1 += c * r1[e]; a2 += c * r2[e]; a3 += c * r3[e];
-        }
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-        if (lane < 4) {
-            const int tau = tb + lane;
-            if (tau < d.Tp) {
-                float v = (lane == 0) ? a0 : (lane == 1) ? a1 : (lane == 2) ? a2 : a3;
-                if (tau >= len) v = 0.f;
-                else if (!last) v += p.datt_next[(long)b * d.Tp + tau];
-                p.dattn[(long)b * d.Tp + tau] = v;
-            }
-        }
-    }
-}
-
-// B2b: softmax backward + energy backward for one (utterance, TT-frame tile).
-// Block = ceil(A/64) waves; wave w OWNS attention dims a = 64w + lane for all TT frames of the tile, so the
-// per-a partial sums (d w_g, d W_proj, d query) have exactly one writer — no atomics (LDS float atomics were
-// measured at ~0.2 us per wave-instruction and dominated this kernel).
+// B2: attention backward of one (utterance, TE-frame tile) in ONE kernel:
+//   dattn[tau] = dctx . enc[tau] + datt_next[tau]                      (context + next step's location path)
+//   softmax backward: de = attn * (dattn - dot) / temperature, with dot = sum_tau attn*dattn over the WHOLE utterance
+//     = dctx . ctx + sum_tau attn*datt_next   (ctx = sum attn*enc is the saved context), so no workgroup needs another
+//     tile's dattn and the former separate dattn kernel + buffer are gone;
+//   energy backward: recompute loc/u from the saved conv, accumulate dkey (RMW), per-workgroup partial sums of
+//     d w_g / d W_proj / d b_g in private slots, d query (x (1-q^2), atomically into dq[b,t,:]) and
+//     dconv[tau,k] = sum_a dl[tau,a] W_proj[a,k], written over the saved conv of this step.
+// Threads: NG frame groups x ceil(A/64) waves; wave (g, wa) owns attention dims a = 64*wa + lane for the frames of
+// group g, so the per-a sums have one writer per group and meet in LDS.  TE is chosen by the host so that the batch is
+// one round of workgroups; all global operands are requested before the first barrier.
 template <int KNMAX>
-__global__ __launch_bounds__(512) void att_bwd_energy_kernel(DecB p, int t, int dbg) {
+__global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int TE, int NG, int last) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    __shared__ float s16[16];
-    __shared__ float s_de[TT];
+    __shared__ float s_red[16];
+    constexpr int KP = (KNMAX + 3) & ~3, CHK = 10;
     const asr_dec_dims_t& d = p.f.d;
-    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
-    const int nthr = blockDim.x, nwave = nthr >> 6;
-    const int taps = 2 * d.Ks + 1;
-    const int AP = d.A | 1;                        // odd row stride of the dloc tile (bank spread)
-    float* s_pa = smem_f;
-    float* s_wc = s_pa + (TT + 2 * d.Ks);
-    float* s_conv = s_wc + d.Kn * taps;
-    float* s_dl = s_conv + d.Kn * TT;              // [TT*AP] gradient wrt the loc pre-activation
-    float* s_wp = s_dl + TT * AP;                  // [A*Kn] W_proj staged once per workgroup
-    float* s_dcw = s_wp + d.A * d.Kn;              // [nwave][Kn*TT] per-wave partial dconv
-    if (!(dbg & 1)) conv_tile(p.f, b, t, tau0, s_pa, s_wc, s_conv);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tau0 = blockIdx.x * TE;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int nwa = (d.A + 63) >> 6, g = wave / nwa, wa = wave - g * nwa;
+    const int FG = TE / NG;                              // frames per group
+    int ap4 = (d.A + 3) >> 2; if ((ap4 & 1) == 0) ++ap4;
+    const int AP = 4 * ap4;                              // row stride of the [frame][a] / [k][a] tiles: 16B rows, odd in float4 units
+    const int XW = d.Dd + d.E;
+    float* s_cv = smem_f;                                // [TE][KP]   conv of the tile
+    float* s_de = s_cv + TE * KP;                        // [TE]
+    float* s_dat = s_de + TE;                            // [TE]
+    float* s_dctx = s_dat + TE;                          // [E]
+    float* s_wpT = s_dctx + ((d.E + 3) & ~3);            // [Kn][AP]
+    float* s_dl = s_wpT + d.Kn * AP;                     // [TE][AP]
+    float* s_acc = s_dl + TE * AP;                       // [NG][Kn+2][A]
     const int len = min((int)p.f.enc_len[b], d.Tp);
-    const float* att = p.f.s.att + ((long)b * d.L + t) * d.Tp;
-    const float* dat = p.dattn + (long)b * d.Tp;
-    // softmax backward needs sum_tau attn*dattn over the whole utterance
-    float dot = 0.f;
-    for (int i = tid; i < len; i += nthr) dot += att[i] * dat[i];
-    dot = wave_sum(dot);
-    if (lane == 0) s16[wave] = dot;
-    for (int i = tid; i < d.A * d.Kn; i += nthr) s_wp[i] = p.f.w.Wproj[i];
-    __syncthreads();
-    dot = 0.f;
-    for (int w = 0; w < nwave; ++w) dot += s16[w];
-    if (tid < TT) {
-        const int tau = tau0 + tid;
-        s_de[tid] = (tau < len) ? att[tau] * (dat[tau] - dot) / d.temperature : 0.f;
-    }
-    __syncthreads();
+    const int tmax = max(len - 1, 0);
+    const long row = (long)b * d.L + t;
+    float* convrow = p.f.s.conv + row * d.Kn * d.Tp;     // conv in, dconv out
+    const float* att = p.f.s.att + row * d.Tp;
+    const float* dnext = p.datt_next + (long)b * d.Tp;
 
-    const int a = 64 * wave + lane;
+    // ---- stage 0: all global reads
+    float dot = 0.f;
+    for (int e = tid; e < d.E; e += nthr) {
+        const float dc = p.dxin[row * XW + d.Dd + e];
+        s_dctx[e] = dc;
+        dot += dc * p.f.s.xin[row * XW + d.Dd + e];
+    }
+    if (!last) for (int i = tid; i < len; i += nthr) dot += att[i] * dnext[i];
+    for (int i = tid; i < d.Kn * TE; i += nthr) {
+        const int k = i / TE, ti = i - k * TE;
+        s_cv[ti * KP + k] = (tau0 + ti < d.Tp) ? convrow[(long)k * d.Tp + tau0 + ti] : 0.f;
+    }
+    for (int i = tid; i < d.Kn * d.A; i += nthr) { const int a = i / d.Kn, k = i - a * d.Kn; s_wpT[k * AP + a] = p.f.w.Wproj[i]; }
+    for (int i = tid; i < d.Kn * (AP - d.A); i += nthr) { const int k = i / (AP - d.A); s_wpT[k * AP + d.A + (i - k * (AP - d.A))] = 0.f; }
+    const int a = 64 * wa + lane;
     const bool aok = a < d.A;
     const int ac = aok ? a : d.A - 1;
-    const int tmax = max(len - 1, 0);
-    float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot;
-    if (!(dbg & 2)) {
-        float wp[KNMAX], dwp[KNMAX];
+    const float qa = p.f.s.q[row * d.A + ac], wga = p.f.w.wg[ac];
+    float* slot = p.slots + ((long)b * p.nte + blockIdx.x) * p.slot;
+    float old[KNMAX + 1];
+    if (g == 0) {
+        old[KNMAX] = slot[ac];
 #pragma unroll
-        for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? s_wp[ac * d.Kn + k] : 0.f; dwp[k] = 0.f; }
-        const float qa = p.f.s.q[((long)b * d.L + t) * d.A + ac], wga = p.f.w.wg[ac];
-        float dwg = 0.f, dqa = 0.f;
-        constexpr int HALF = TT / 2;
-#pragma unroll 1
-        for (int h0 = 0; h0 < TT; h0 += HALF) {
-            // key / dkey of this lane's column for HALF frames: all loads in flight, no other global reads in the loop
-            float kv[HALF], dk[HALF];
+        for (int k = 0; k < KNMAX; ++k) old[k] = (k < d.Kn) ? slot[d.A + k * d.A + ac] : 0.f;
+    }
+    float kv[CHK], dk[CHK];
+    const int f_beg = g * FG, f_end = f_beg + FG;
+    auto load_chunk = [&](int f0) {
 #pragma unroll
-            for (int i = 0; i < HALF; ++i) {
-                const long ki = ((long)b * d.Tp + min(tau0 + h0 + i, tmax)) * d.A + ac;
-                kv[i] = p.f.s.key[ki];
-                dk[i] = p.dkey[ki];
+        for (int i = 0; i < CHK; ++i) {
+            const long ki = ((long)b * d.Tp + min(tau0 + f0 + i, tmax)) * d.A + ac;
+            kv[i] = p.f.s.key[ki];
+            dk[i] = p.dkey[ki];
+        }
+    };
+    load_chunk(f_beg);
+    __syncthreads();
+    // ---- stage 1: dattn of the tile (16 lanes per frame, float4 over E), block-wide dot, de
+    {
+        const int part = tid & 15;
+        const bool vec = (d.E & 3) == 0;
+        for (int f = tid >> 4; f < TE; f += nthr >> 4) {
+            const int tau = tau0 + f;
+            const float* er = p.f.enc + ((long)b * d.Tp + min(tau, tmax)) * d.E;
+            float v = 0.f;
+            if (vec) {
+                for (int e = 4 * part; e < d.E; e += 64) {
+                    const float4 x = *reinterpret_cast<const float4*>(er + e);
+                    const float4 c = *reinterpret_cast<const float4*>(s_dctx + e);
+                    v += x.x * c.x + x.y * c.y + x.z * c.z + x.w * c.w;
+                }
+            } else {
+                for (int e = part; e < d.E; e += 16) v += er[e] * s_dctx[e];
             }
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            if (part == 0) s_dat[f] = (tau < len) ? v + (last ? 0.f : dnext[tau]) : 0.f;
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) s_red[wave] = dot;
+    }
+    __syncthreads();
+    dot = 0.f;
+    for (int w = 0; w < (nthr >> 6); ++w) dot += s_red[w];
+    for (int f = tid; f < TE; f += nthr) {
+        const int tau = tau0 + f;
+        s_de[f] = (tau < len) ? att[tau] * (s_dat[f] - dot) / d.temperature : 0.f;
+    }
+    __syncthreads();
+    // ---- stage 2: sweep over the group's frames
+    float wp[KNMAX], dwp[KNMAX];
 #pragma unroll
-            for (int i = 0; i < HALF; ++i) {
-                const int ti = h0 + i, tau = tau0 + ti;
+    for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < d.Kn) ? s_wpT[k * AP + ac] : 0.f; dwp[k] = 0.f; }
+    float dwg = 0.f, dqa = 0.f;
+    for (int f0 = f_beg; f0 < f_end; f0 += CHK) {
+        float kc[CHK], dc_[CHK];
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) { kc[i] = kv[i]; dc_[i] = dk[i]; }
+        if (f0 + CHK < f_end) load_chunk(f0 + CHK);          // next chunk in flight during this one
+#pragma unroll
+        for (int i = 0; i < CHK; ++i) {
+            const int f = f0 + i, tau = tau0 + f;
+            if (f < f_end) {
+                float cvv[KP];
+#pragma unroll
+                for (int k4 = 0; k4 < KP; k4 += 4) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(s_cv + f * KP + k4);
+                    cvv[k4] = c4.x; cvv[k4 + 1] = c4.y; cvv[k4 + 2] = c4.z; cvv[k4 + 3] = c4.w;
+                }
                 float lp = 0.f;
 #pragma unroll
-                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * s_conv[k * TT + ti];
+                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * cvv[k];
                 const float loc = tanh_fast(lp);
-                const float u = tanh_fast(kv[i] + qa + loc);
-                const float de = s_de[ti];                       // 0 for tau >= len
+                const float u = tanh_fast(kc[i] + qa + loc);
+                const float de = s_de[f];                        // 0 for tau >= len
                 const float du = de * wga * (1.f - u * u);
                 const float dl = du * (1.f - loc * loc);
                 dwg += de * u;
                 dqa += du;
 #pragma unroll
-                for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * s_conv[k * TT + ti];
-                if (aok && tau < len) p.dkey[((long)b * d.Tp + tau) * d.A + a] = dk[i] + du;
-                if (aok) s_dl[ti * AP + a] = dl;
+                for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * cvv[k];
+                if (aok && tau < len) p.dkey[((long)b * d.Tp + tau) * d.A + a] = dc_[i] + du;
+                if (aok) s_dl[f * AP + a] = dl;
             }
         }
-        if (aok) {
-            // single owner of (a): per-workgroup slot accumulated across steps, query partial of this step
-            // (all loads first, then all stores: a chain of `slot[i] += x` is a chain of dependent round trips)
-            float old[KNMAX + 1];
-            old[KNMAX] = slot[a];
+    }
+    if (wa == nwa - 1) {                                     // zero the pad columns of the dl tile (read as float4 below)
+        for (int f = f_beg; f < f_end; ++f)
+            for (int x = d.A + lane; x < AP; x += 64) s_dl[f * AP + x] = 0.f;
+    }
+    if (NG > 1 && aok) {
+        float* acc = s_acc + (long)g * (d.Kn + 2) * d.A;
+        acc[a] = dwg; acc[d.A + a] = dqa;
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) old[k] = (k < d.Kn) ? slot[d.A + k * d.A + a] : 0.f;   // [k][a]: lanes contiguous
-            slot[a] = old[KNMAX] + dwg;
-#pragma unroll
-            for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) slot[d.A + k * d.A + a] = old[k] + dwp[k];
-            p.dqpart[((long)b * p.ntiles + blockIdx.x) * d.A + a] = dqa;
-        }
+        for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) acc[(2 + k) * d.A + a] = dwp[k];
     }
     __syncthreads();
-    // dconv[tau,k] = sum_a dl[tau,a] * Wproj[a,k]: thread (frame ti = lane % TT, chunk = wave*(64/TT) + lane / TT)
-    {
-        constexpr int CPW = 64 / TT;                  // chunks per wave
-        const int nch = nwave * CPW;
-        const int ti = lane % TT, ch = wave * CPW + lane / TT;
-        const int a_per = (d.A + nch - 1) / nch;
-        const int a_beg = ch * a_per, a_end = min(d.A, a_beg + a_per);
-        float acc[KNMAX];
+    if (g == 0 && aok) {
+        for (int gg = 1; gg < NG; ++gg) {
+            const float* acc = s_acc + (long)gg * (d.Kn + 2) * d.A;
+            dwg += acc[a]; dqa += acc[d.A + a];
 #pragma unroll
-        for (int k = 0; k < KNMAX; ++k) acc[k] = 0.f;
-        for (int x = a_beg; x < a_end && !(dbg & 4); ++x) {
-            const float dl = s_dl[ti * AP + x];
+            for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) dwp[k] += acc[(2 + k) * d.A + a];
+        }
+        slot[a] = old[KNMAX] + dwg;
 #pragma unroll
-            for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) acc[k] += dl * s_wp[x * d.Kn + k];
-        }
-#pragma unroll
-        for (int k = 0; k < KNMAX; ++k) {
-            float v = acc[k];
-            for (int o = TT; o < 64; o <<= 1) v += __shfl_xor(v, o);      // the wave's chunks
-            if (k < d.Kn && lane < TT) s_dcw[(wave * d.Kn + k) * TT + ti] = v;
-        }
-        __syncthreads();
-        for (int o = tid; o < d.Kn * TT; o += nthr) {
-            const int t2 = o % TT, k = o / TT;
-            float v = 0.f;
-            for (int w = 0; w < nwave; ++w) v += s_dcw[(w * d.Kn + k) * TT + t2];
-            const int tau = tau0 + t2;
-            if (tau < d.Tp) p.dconv[((long)b * d.Kn + k) * d.Tp + tau] = (tau < len) ? v : 0.f;
-        }
+        for (int k = 0; k < KNMAX; ++k) if (k < d.Kn) slot[d.A + k * d.A + a] = old[k] + dwp[k];
+        atomicAdd(&p.dq[row * d.A + a], dqa * (1.f - qa * qa));
     }
-    // d b_g partial
-    if (tid < 64) {
-        float sde = (tid < TT) ? s_de[tid] : 0.f;
-        sde = wave_sum(sde);
-        if (tid == 0) slot[d.A * (1 + d.Kn)] += sde;
+    if (tid == 0) {
+        float sde = 0.f;
+        for (int f = 0; f < TE; ++f) sde += s_de[f];
+        slot[d.A * (1 + d.Kn)] += sde;
+    }
+    // ---- stage 3: dconv[tau,k] = sum_a dl[tau,a] * W_proj[a,k]  (thread per (frame, k), float4 over a)
+    for (int o = tid; o < TE * d.Kn; o += nthr) {
+        const int f = o % TE, k = o / TE;
+        const float4* dl4 = reinterpret_cast<const float4*>(s_dl + f * AP);
+        const float4* w4 = reinterpret_cast<const float4*>(s_wpT + k * AP);
+        float v0 = 0.f, v1 = 0.f;
+        int x = 0;
+        for (; x + 1 < ap4; x += 2) {
+            const float4 d0 = dl4[x], w0 = w4[x], d1 = dl4[x + 1], w1 = w4[x + 1];
+            v0 += d0.x * w0.x + d0.y * w0.y + d0.z * w0.z + d0.w * w0.w;
+            v1 += d1.x * w1.x + d1.y * w1.y + d1.z * w1.z + d1.w * w1.w;
+        }
+        if (x < ap4) { const float4 d0 = dl4[x], w0 = w4[x]; v0 += d0.x * w0.x + d0.y * w0.y + d0.z * w0.z + d0.w * w0.w; }
+        const int tau = tau0 + f;
+        if (tau < d.Tp) convrow[(long)k * d.Tp + tau] = (tau < len) ? v0 + v1 : 0.f;
     }
 }
 
-// B2c: gradient through the location convolution: datt_next (wrt attn_{t-1}) and d W_conv partials
-__global__ __launch_bounds__(256) void att_bwd_conv_kernel(DecB p, int t) {
+// B3: gradient through the location convolution wrt attn_{t-1}:
+//   datt_next[tau'] = sum_k sum_j W[k][j] * dconv[k][tau' - j + Ks]      (dconv = this step's rows of state.conv)
+// grid (ceil(T'/TC), B), 512 threads; item = (tap range, k, group of 4 outputs) with a sliding register window.
+// (d W_conv needs no place in the sequential chain: wconv_grad_kernel after the loop.)
+__global__ __launch_bounds__(512) void att_bwd_conv_kernel(DecB p, int t, int TC) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const asr_dec_dims_t& d = p.f.d;
-    const int b = blockIdx.y, tau0 = blockIdx.x * TT;
-    const int taps = 2 * d.Ks + 1, win = TT + 2 * d.Ks;
-    const int len = min((int)p.f.enc_len[b], d.Tp);
-    float* s_wc = smem_f;                    // [Kn*taps]
-    float* s_dc = s_wc + d.Kn * taps;        // [Kn*win]  dconv window tau0-Ks .. tau0+TT+Ks
-    float* s_pa = s_dc + d.Kn * win;         // [win]     prev_att window (for d W_conv)
-    for (int i = threadIdx.x; i < d.Kn * taps; i += 256) s_wc[i] = p.f.w.Wconv[i];
-    for (int i = threadIdx.x; i < d.Kn * win; i += 256) {
-        const int k = i / win, tau = tau0 + (i % win) - d.Ks;
-        s_dc[i] = (tau >= 0 && tau < d.Tp) ? p.dconv[((long)b * d.Kn + k) * d.Tp + tau] : 0.f;
+    const int b = blockIdx.y, tau0 = blockIdx.x * TC, tid = threadIdx.x;
+    const int taps = 2 * d.Ks + 1, win = TC + 2 * d.Ks;
+    float* s_wc = smem_f;                                // [Kn*taps]
+    float* s_dc = s_wc + ((d.Kn * taps + 3) & ~3);       // [Kn][win+4]  dconv window tau0-Ks .. tau0+TC+Ks
+    const int winp = win + 4;
+    float* s_part = s_dc + d.Kn * winp;                  // [parts*Kn][TC]
+    const float* dconv = p.f.s.conv + ((long)b * d.L + t) * d.Kn * d.Tp;
+    for (int i = tid; i < d.Kn * taps; i += 512) s_wc[i] = p.f.w.Wconv[i];
+    for (int i = tid; i < d.Kn * winp; i += 512) {
+        const int k = i / winp, x = i - k * winp, tau = tau0 + x - d.Ks;
+        s_dc[i] = (x < win && tau >= 0 && tau < d.Tp) ? dconv[(long)k * d.Tp + tau] : 0.f;
     }
-    const float* prev = (t > 0) ? p.f.s.att + ((long)b * d.L + (t - 1)) * d.Tp : nullptr;
-    for (int i = threadIdx.x; i < win; i += 256) {
-        const int tau = tau0 + i - d.Ks;
+    __syncthreads();
+    const int ngrp = TC / 4, nout = d.Kn * ngrp;
+    const int parts = max(1, min(8, 512 / nout));
+    const int tp = (taps + parts - 1) / parts;
+    for (int it = tid; it < parts * nout; it += 512) {
+        const int pz = it / nout, o = it - pz * nout, k = o / ngrp, ig = o - k * ngrp;
+        const int j0 = pz * tp, j1 = min(taps, j0 + tp);
+        const float* wk = s_wc + k * taps;
+        const float* dc = s_dc + k * winp + 4 * ig + 2 * d.Ks;      // dc[i - j] for output i of the group
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        if (j0 < j1) { p1 = dc[1 - j0]; p2 = dc[2 - j0]; p3 = dc[3 - j0]; }
+        for (int j = j0; j < j1; ++j) {
+            const float w = wk[j], p0 = dc[-j];
+            a0 += w * p0; a1 += w * p1; a2 += w * p2; a3 += w * p3;
+            p3 = p2; p2 = p1; p1 = p0;
+        }
+        float* o4 = s_part + (long)(pz * d.Kn + k) * TC + 4 * ig;
+        o4[0] = a0; o4[1] = a1; o4[2] = a2; o4[3] = a3;
+    }
+    __syncthreads();
+    for (int i = tid; i < TC; i += 512) {
         float v = 0.f;
-        if (tau >= 0 && tau < d.Tp) v = prev ? prev[tau] : (tau < len ? 1.f / (float)len : 0.f);
-        s_pa[i] = v;
-    }
-    __syncthreads();
-    // conv[k][tau] = sum_j W[k][j] pa[tau + j - Ks]  =>  d pa[tau'] = sum_k sum_j W[k][j] dconv[k][tau' - j + Ks]
-    // 4 thread groups split the kernels k; partial sums meet in LDS
-    __shared__ float s_red[256 / TT][TT];
-    {
-        constexpr int NKG = 256 / TT;
-        const int i = threadIdx.x % TT, kg = threadIdx.x / TT;
-        float acc = 0.f;
-        if (t > 0) {
-            for (int k = kg; k < d.Kn; k += NKG) {
-                const float* wk = s_wc + k * taps;
-                const float* dc = s_dc + k * win + i + 2 * d.Ks;   // window index of tau' + Ks
-                for (int j = 0; j < taps; ++j) acc += wk[j] * dc[-j];
-            }
-        }
-        s_red[kg][i] = acc;
-    }
-    __syncthreads();
-    if (t > 0 && threadIdx.x < TT) {
-        const int tau = tau0 + threadIdx.x;
-        if (tau < d.Tp)
-        {
-            float v = 0.f;
-#pragma unroll
-            for (int g = 0; g < 256 / TT; ++g) v += s_red[g][threadIdx.x];
-            p.datt_next[(long)b * d.Tp + tau] = v;
-        }
-    }
-    // d W_conv[k][j] += sum_{tau in tile} dconv[k][tau] * pa[tau + j - Ks]   (sums first, then one batched read-modify-write)
-    float* slot = p.slots + ((long)b * p.ntiles + blockIdx.x) * p.slot + d.A * (1 + d.Kn) + 1;
-    constexpr int NO = 10;                         // outputs per thread per pass
-    for (int o0 = threadIdx.x; o0 < d.Kn * taps; o0 += 256 * NO) {
-        float acc[NO], old[NO];
-#pragma unroll
-        for (int u = 0; u < NO; ++u) {
-            const int o = o0 + 256 * u;
-            acc[u] = 0.f;
-            if (o < d.Kn * taps) {
-                const int k = o / taps, j = o % taps;
-                float a = 0.f;
-                for (int i = 0; i < TT; ++i) a += s_dc[k * win + d.Ks + i] * s_pa[i + j];
-                acc[u] = a;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NO; ++u) { const int o = o0 + 256 * u; old[u] = (o < d.Kn * taps) ? slot[o] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < NO; ++u) { const int o = o0 + 256 * u; if (o < d.Kn * taps) slot[o] = old[u] + acc[u]; }
+        for (int r = 0; r < parts * d.Kn; ++r) v += s_part[(long)r * TC + i];
+        if (tau0 + i < d.Tp) p.datt_next[(long)b * d.Tp + tau0 + i] = v;
     }
 }
 
-// B3: query backward.  dq[b,t,:] <- dq * (1 - q^2) (kept for the batched dW_q);  dhs[b,t-1,:] += that * W_q.
-__global__ __launch_bounds__(256) void dq_pre_kernel(DecB p, int t) {
-    // grid (ceil(A/64), B): 4 waves split the tiles of the utterance, lanes over 64 attention dims
-    __shared__ float red[4][64];
-    const asr_dec_dims_t& d = p.f.d;
-    const int b = blockIdx.y, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int a = blockIdx.x * 64 + lane;
-    float acc = 0.f;
-    if (a < d.A) {
-#pragma unroll 4
-        for (int tl = grp; tl < p.ntiles; tl += 4) acc += p.dqpart[((long)b * p.ntiles + tl) * d.A + a];
+// d W_conv[k][j] += sum_{l,b} sum_tau dconv_l[b,k,tau] * prev_att_l[b, tau + j - Ks]   after the loop, all steps at once.
+// grid (NCH, B): workgroup (c, b) walks the steps l = c, c+NCH, ...; thread (k, group of 4 taps) slides over tau.
+// Partial sums per workgroup land in `out` (gridDim.x*gridDim.y, Kn*taps) and are reduced by slot_reduce_kernel.
+__global__ __launch_bounds__(512) void wconv_grad_kernel(DecP p, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const asr_dec_dims_t& d = p.d;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int taps = 2 * d.Ks + 1;
+    const int tg = (taps + 3) / 4, nitem = d.Kn * tg;
+    const int len = min((int)p.enc_len[b], d.Tp);
+    const int wpa = d.Tp + 2 * d.Ks + 8;
+    float* s_pa = smem_f;                                // [Tp + 2Ks + 8]  zero-padded previous attention
+    float* s_dc = s_pa + ((wpa + 3) & ~3);               // [Kn][Tp]
+    float acc[4][4];                                     // up to 4 items per thread
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.f; }
+    for (int l = blockIdx.x; l < d.L; l += gridDim.x) {
+        __syncthreads();
+        const float* prev = (l > 0) ? p.s.att + ((long)b * d.L + (l - 1)) * d.Tp : nullptr;
+        const float uni = 1.f / (float)max(len, 1);
+        for (int i = tid; i < wpa; i += 512) {
+            const int tau = i - d.Ks;
+            float v = 0.f;
+            if (tau >= 0 && tau < d.Tp) v = prev ? prev[tau] : (tau < len ? uni : 0.f);
+            s_pa[i] = v;
+        }
+        const float* dconv = p.s.conv + ((long)b * d.L + l) * d.Kn * d.Tp;
+        for (int i = tid; i < d.Kn * d.Tp; i += 512) s_dc[i] = dconv[i];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = tid + 512 * u;
+            if (it < nitem) {
+                const int k = it / tg, j0 = 4 * (it - k * tg);
+                const float* dc = s_dc + k * d.Tp;
+                const float* pa = s_pa + j0;                 // pa[tau + jj] = prev_att[tau + j0 + jj - Ks]
+                float q0 = pa[0], q1 = pa[1], q2 = pa[2];
+                float a0 = acc[u][0], a1 = acc[u][1], a2 = acc[u][2], a3 = acc[u][3];
+                for (int tau = 0; tau < len; ++tau) {
+                    const float w = dc[tau], q3 = pa[tau + 3];
+                    a0 += w * q0; a1 += w * q1; a2 += w * q2; a3 += w * q3;
+                    q0 = q1; q1 = q2; q2 = q3;
+                }
+                acc[u][0] = a0; acc[u][1] = a1; acc[u][2] = a2; acc[u][3] = a3;
+            }
+        }
     }
-    red[grp][lane] = acc;
-    __syncthreads();
-    if (grp == 0 && a < d.A) {
-        const long idx = ((long)b * d.L + t) * d.A + a;
-        const float qv = p.f.s.q[idx];
-        p.dq[idx] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * (1.f - qv * qv);
+    float* o = out + ((long)blockIdx.y * gridDim.x + blockIdx.x) * d.Kn * taps;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = tid + 512 * u;
+        if (it < nitem) {
+            const int k = it / tg, j0 = 4 * (it - k * tg);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) if (j0 + jj < taps) o[k * taps + j0 + jj] = acc[u][jj];
+        }
     }
 }
+
+// B4: query backward.  dq[b,t,:] already holds the gradient wrt the query pre-activation;  dhs[b,t-1,:] += dq * W_q.
 template <bool BF16>
 __global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t) {
     __shared__ float red[4][256];
@@ -769,28 +865,63 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdLayout {
-    size_t dhs, dxin, dq, dkey, dattn, datt_next, dconv, dcf, wq_t, slots, dkeypre, dqpart, wcat[ASR_MAX_DEC_LAYERS], total;
-    int ntiles, slot;
+    size_t dhs, dxin, dq, dkey, datt_next, dcf, wq_t, slots, wslots, dkeypre, wcat[ASR_MAX_DEC_LAYERS], total;
+    int nte, slot;          // energy-backward tiles per utterance, floats per slot
+    int TE, NG;             // frames per energy-backward workgroup, frame groups
+    int TC;                 // outputs per conv-backward workgroup
+    int nch;                // step chunks of the W_conv gradient kernel
+    size_t lds_e, lds_c, lds_w;
 };
 BwdLayout bwd_layout(const asr_dec_dims_t& d) {
     BwdLayout o;
     size_t off = 0;
     auto take = [&](size_t nfloat) { size_t r = off; off += align_up(nfloat * sizeof(float)); return r; };
     const int XW = d.Dd + d.E;
-    o.ntiles = cdiv(d.Tp, TT);
-    o.slot = d.A * (1 + d.Kn) + 1 + d.Kn * (2 * d.Ks + 1);
+    const int taps = 2 * d.Ks + 1;
+    // energy backward: NG frame groups x ceil(A/64) waves (<= 640 threads); the smallest tile that keeps the batch in
+    // one round of workgroups and fits the LDS budget
+    const int nwa = cdiv(d.A, 64);
+    o.NG = nwa <= 2 ? 4 : (nwa <= 5 ? 2 : 1);
+    int ap4 = (d.A + 3) / 4; if ((ap4 & 1) == 0) ++ap4;
+    const int AP = 4 * ap4, KP = 16;
+    auto lds_of = [&](int te) {
+        return sizeof(float) * ((size_t)te * KP + 2 * (size_t)te + ((d.E + 3) & ~3) + (size_t)d.Kn * AP + (size_t)te * AP +
+                                (size_t)o.NG * (d.Kn + 2) * d.A);
+    };
+    const int te_cand[] = {8, 16, 24, 32, 40, 48, 64};
+    o.TE = 8;
+    for (int i = 0; i < 7; ++i) {
+        const int te = te_cand[i];
+        if (lds_of(te) > 150 * 1024) break;
+        o.TE = te;
+        if ((long)d.B * cdiv(d.Tp, te) <= 256) break;
+    }
+    o.lds_e = lds_of(o.TE);
+    o.nte = cdiv(d.Tp, o.TE);
+    o.slot = d.A * (1 + d.Kn) + 1;
+    // conv backward
+    const int tc_cand[] = {8, 16, 24, 32, 40, 48, 64};
+    o.TC = 64;
+    for (int i = 0; i < 7; ++i) if ((long)d.B * cdiv(d.Tp, tc_cand[i]) <= 256) { o.TC = tc_cand[i]; break; }
+    {
+        const int nout = d.Kn * (o.TC / 4);
+        const int parts = nout >= 512 ? 1 : (512 / nout > 8 ? 8 : 512 / nout);
+        o.lds_c = sizeof(float) * ((size_t)((d.Kn * taps + 3) & ~3) + (size_t)d.Kn * (o.TC + 2 * d.Ks + 4) + (size_t)parts * d.Kn * o.TC);
+    }
+    // W_conv gradient
+    o.nch = (int)(256 / d.B > 0 ? 256 / d.B : 1);
+    if (o.nch > d.L) o.nch = d.L;
+    o.lds_w = sizeof(float) * ((size_t)((d.Tp + 2 * d.Ks + 8 + 3) & ~3) + (size_t)d.Kn * d.Tp);
     o.dhs = take((size_t)d.B * d.L * d.NL * d.Dd);
     o.dxin = take((size_t)d.B * d.L * XW);
     o.dq = take((size_t)d.B * d.L * d.A);
     o.dkey = take((size_t)d.B * d.Tp * d.A);
     o.dkeypre = take((size_t)d.B * d.Tp * d.A);
-    o.dattn = take((size_t)d.B * d.Tp);
     o.datt_next = take((size_t)d.B * d.Tp);
-    o.dconv = take((size_t)d.B * d.Kn * d.Tp);
-    o.dqpart = take((size_t)d.B * o.ntiles * d.A);
     o.dcf = take((size_t)d.NL * d.B * d.Dd);
     o.wq_t = take((size_t)d.Q * d.A);
-    o.slots = take((size_t)d.B * o.ntiles * o.slot);
+    o.slots = take((size_t)d.B * o.nte * o.slot);
+    o.wslots = take((size_t)d.B * o.nch * d.Kn * taps);
     for (int l = 0; l < d.NL; ++l) o.wcat[l] = take((size_t)((l == 0 ? XW : d.Dd) + d.Dd) * 4 * d.Dd);
     o.total = off;
     return o;
@@ -805,6 +936,41 @@ int check_dims(const asr_dec_dims_t& d, const char* who) {
     ASR_REQUIRE(d.temperature > 0.f, ASR_E_ARG, "%s: temperature must be > 0", who);
     ASR_REQUIRE(d.Tp <= 12000, ASR_E_UNSUPPORTED, "%s: T'=%d exceeds the LDS row budget", who, d.Tp);
     return ASR_OK;
+}
+
+// Launch geometry of the forward energy kernel: the smallest frames-per-wave count that puts the whole batch in one
+// round of workgroups (<= 256), within the register budget of the (KNMAX, TPW) instantiations.
+struct EnergyPlan { int tpw; dim3 grid; size_t lds; };
+EnergyPlan energy_plan(const asr_dec_dims_t& d) {
+    const int cand_small[] = {2, 4, 5, 8}, cand_big[] = {2, 4, 5};
+    const int* cand = (d.Kn <= 4) ? cand_small : cand_big;
+    const int nc = (d.Kn <= 4) ? 4 : (d.Kn <= 10 ? 3 : 2);
+    int tpw = cand[nc - 1];
+    for (int i = 0; i < nc; ++i)
+        if ((long)d.B * cdiv(d.Tp, 8 * cand[i]) <= 256) { tpw = cand[i]; break; }
+    EnergyPlan pl;
+    pl.tpw = tpw;
+    const int TE = 8 * tpw, taps = 2 * d.Ks + 1, win = TE + 2 * d.Ks;
+    pl.grid = dim3(cdiv(d.Tp, TE), d.B);
+    const int nout = d.Kn * (TE / 4);
+    const int parts = nout >= 512 ? 1 : (512 / nout > 8 ? 8 : 512 / nout);
+    pl.lds = sizeof(float) * ((size_t)((win + 3) & ~3) + ((d.Kn * taps + 3) & ~3) + (size_t)d.Kn * TE + ((d.Kn * d.A + 3) & ~3) +
+                              (size_t)parts * d.Kn * TE);
+    return pl;
+}
+template <int KNMAX>
+void launch_energy_k(const DecP& p, int t, const EnergyPlan& pl, hipStream_t st) {
+    switch (pl.tpw) {
+        case 2: hipLaunchKernelGGL((att_energy_kernel<KNMAX, 2>), pl.grid, dim3(512), pl.lds, st, p, t); break;
+        case 4: hipLaunchKernelGGL((att_energy_kernel<KNMAX, 4>), pl.grid, dim3(512), pl.lds, st, p, t); break;
+        case 5: if constexpr (KNMAX <= 10) { hipLaunchKernelGGL((att_energy_kernel<KNMAX, 5>), pl.grid, dim3(512), pl.lds, st, p, t); } break;
+        default: if constexpr (KNMAX <= 4) { hipLaunchKernelGGL((att_energy_kernel<KNMAX, 8>), pl.grid, dim3(512), pl.lds, st, p, t); } break;
+    }
+}
+void launch_energy(const DecP& p, int t, const EnergyPlan& pl, hipStream_t st) {
+    if (p.d.Kn <= 4) launch_energy_k<4>(p, t, pl, st);
+    else if (p.d.Kn <= 10) launch_energy_k<10>(p, t, pl, st);
+    else launch_energy_k<16>(p, t, pl, st);
 }
 
 }  // namespace
@@ -834,18 +1000,15 @@ extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_wei
         hipMemsetAsync(state->tokens, 0, sizeof(int64_t) * d.B * d.L, st);
     }
 
-    const int taps = 2 * d.Ks + 1;
-    const size_t lds_energy = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT);
-    const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
+    const EnergyPlan epl = energy_plan(d);
+    ASR_REQUIRE(epl.lds <= 64 * 1024, ASR_E_UNSUPPORTED, "asr_att_decoder_fwd: energy tile needs %zu B of LDS", epl.lds);
     for (int t = 0; t < d.L; ++t) {
         if (!teacher)
             hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens,
                                state->xin, d.B, d.L, d.Dd, XW, t, 1, d.V);
         if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
         else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
-        if (d.Kn <= 4)       hipLaunchKernelGGL(att_energy_kernel<4>, grid_tile, dim3(256), lds_energy, st, p, t);
-        else if (d.Kn <= 10) hipLaunchKernelGGL(att_energy_kernel<10>, grid_tile, dim3(256), lds_energy, st, p, t);
-        else                 hipLaunchKernelGGL(att_energy_kernel<16>, grid_tile, dim3(256), lds_energy, st, p, t);
+        launch_energy(p, t, epl, st);
         hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
         for (int l = 0; l < d.NL; ++l) {
             if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
@@ -887,16 +1050,13 @@ extern "C" int asr_att_decoder_step(const asr_dec_dims_t* dims, const asr_dec_we
     DecP p{d, *weights, *state, enc, enc_len};
     const int XW = d.Dd + d.E;
     const bool bf = (prec == ASR_BF16);
-    const int taps = 2 * d.Ks + 1;
-    const size_t lds_energy = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT);
-    const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
+    const EnergyPlan epl = energy_plan(d);
+    ASR_REQUIRE(epl.lds <= 64 * 1024, ASR_E_UNSUPPORTED, "asr_att_decoder_step: energy tile needs %zu B of LDS", epl.lds);
     hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens, state->xin,
                        d.B, d.L, d.Dd, XW, t, 1, d.V);
     if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
     else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
-    if (d.Kn <= 4)       hipLaunchKernelGGL(att_energy_kernel<4>, grid_tile, dim3(256), lds_energy, st, p, t);
-    else if (d.Kn <= 10) hipLaunchKernelGGL(att_energy_kernel<10>, grid_tile, dim3(256), lds_energy, st, p, t);
-    else                 hipLaunchKernelGGL(att_energy_kernel<16>, grid_tile, dim3(256), lds_energy, st, p, t);
+    launch_energy(p, t, epl, st);
     hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
     for (int l = 0; l < d.NL; ++l) {
         if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
@@ -937,16 +1097,18 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     p.f = DecP{d, *weights, *state, enc, enc_len};
     p.g = *grads;
     p.dhs = (float*)(ws + lay.dhs); p.dxin = (float*)(ws + lay.dxin); p.dq = (float*)(ws + lay.dq);
-    p.dkey = (float*)(ws + lay.dkey); p.dattn = (float*)(ws + lay.dattn); p.datt_next = (float*)(ws + lay.datt_next);
-    p.dconv = (float*)(ws + lay.dconv); p.dqpart = (float*)(ws + lay.dqpart); p.dcf = (float*)(ws + lay.dcf); p.wqT = (float*)(ws + lay.wq_t);
-    p.slots = (float*)(ws + lay.slots); p.ntiles = lay.ntiles; p.slot = lay.slot;
+    p.dkey = (float*)(ws + lay.dkey); p.datt_next = (float*)(ws + lay.datt_next);
+    p.dcf = (float*)(ws + lay.dcf); p.wqT = (float*)(ws + lay.wq_t);
+    p.slots = (float*)(ws + lay.slots); p.nte = lay.nte; p.slot = lay.slot;
+    float* wslots = (float*)(ws + lay.wslots);
     float* dkeypre = (float*)(ws + lay.dkeypre);
     for (int l = 0; l < ASR_MAX_DEC_LAYERS; ++l) p.wcatT[l] = (l < d.NL) ? (float*)(ws + lay.wcat[l]) : nullptr;
 
     // zero-initialised accumulators: dhs, dq, dkey, slots  (dxin is fully written by the loop)
     hipMemsetAsync(p.dhs, 0, sizeof(float) * (size_t)BL * SW, st);
     hipMemsetAsync(p.dkey, 0, sizeof(float) * (size_t)d.B * d.Tp * d.A, st);
-    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * lay.ntiles * lay.slot, st);
+    hipMemsetAsync(p.dq, 0, sizeof(float) * (size_t)BL * d.A, st);
+    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * lay.nte * lay.slot, st);
 
     // transposed weights so that every per-step contraction is K-contiguous
     for (int l = 0; l < d.NL; ++l) {
@@ -969,23 +1131,23 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     if (rc != ASR_OK) return rc;
 
     const int taps = 2 * d.Ks + 1;
-    const dim3 grid_tile(cdiv(d.Tp, TT), d.B);
     const int nw_e = cdiv(d.A, 64);
-    ASR_REQUIRE(nw_e <= 8, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: attention dim %d > 512", d.A);
-    const size_t lds_e = sizeof(float) * ((TT + 2 * d.Ks) + (size_t)d.Kn * taps + (size_t)d.Kn * TT + (size_t)TT * (d.A | 1) +
-                                          (size_t)d.A * d.Kn + (size_t)nw_e * d.Kn * TT);
-    const size_t lds_c = sizeof(float) * ((size_t)d.Kn * taps + (size_t)(d.Kn + 1) * (TT + 2 * d.Ks));
-    ASR_REQUIRE(lds_e <= 160 * 1024 - 1024, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: attention dim %d needs %zu B of LDS", d.A, lds_e);
+    ASR_REQUIRE(state->conv, ASR_E_ARG, "asr_att_decoder_bwd: state->conv (saved location convolution) is NULL");
+    ASR_REQUIRE(nw_e * lay.NG <= 10, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: attention dim %d > 640", d.A);
+    ASR_REQUIRE(d.Kn * ((taps + 3) / 4) <= 2048, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: location filter bank %d x %d too large", d.Kn, taps);
+    ASR_REQUIRE(lay.lds_e <= 150 * 1024 && lay.lds_c <= 150 * 1024 && lay.lds_w <= 150 * 1024, ASR_E_UNSUPPORTED,
+                "asr_att_decoder_bwd: shape needs %zu / %zu / %zu B of LDS", lay.lds_e, lay.lds_c, lay.lds_w);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)att_bwd_energy_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         hipFuncSetAttribute((const void*)att_bwd_energy_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         hipFuncSetAttribute((const void*)att_bwd_energy_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)wconv_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_set = true;
     }
-
-    const char* dbg_env = getenv("ASR_DEBUG_SKIP");
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;      // timing ablation only (results are wrong when set)
+    const dim3 grid_e(lay.nte, d.B), block_e(64 * nw_e * lay.NG);
+    const dim3 grid_c(cdiv(d.Tp, lay.TC), d.B);
     for (int t = d.L - 1; t >= 0; --t) {
         const int last = (t == d.L - 1);
         for (int l = d.NL - 1; l >= 0; --l) {
@@ -994,13 +1156,12 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
             if (bf) hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<true>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
             else    hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<false>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
         }
-        hipLaunchKernelGGL(att_bwd_dattn_kernel, grid_tile, dim3(256), sizeof(float) * d.E, st, p, t, last);
-        if (d.Kn <= 4)       hipLaunchKernelGGL(att_bwd_energy_kernel<4>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
-        else if (d.Kn <= 10) hipLaunchKernelGGL(att_bwd_energy_kernel<10>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
-        else                 hipLaunchKernelGGL(att_bwd_energy_kernel<16>, grid_tile, dim3(64 * nw_e), lds_e, st, p, t, dbg);
-        hipLaunchKernelGGL(att_bwd_conv_kernel, grid_tile, dim3(256), lds_c, st, p, t);
-        hipLaunchKernelGGL(dq_pre_kernel, dim3(cdiv(d.A, 64), d.B), dim3(256), 0, st, p, t);
+        if (d.Kn <= 4)       hipLaunchKernelGGL(att_bwd_energy_kernel<4>, grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+        else if (d.Kn <= 10) hipLaunchKernelGGL(att_bwd_energy_kernel<10>, grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+        else                 hipLaunchKernelGGL(att_bwd_energy_kernel<16>, grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
         if (t > 0) {
+            // the location path reaches attn_{t-1}; step 0 convolves the constant initial attention
+            hipLaunchKernelGGL(att_bwd_conv_kernel, grid_c, dim3(512), lay.lds_c, st, p, t, lay.TC);
             if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);
             else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);
         }
@@ -1046,13 +1207,14 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     if (rc != ASR_OK) return rc;
     rc = asr_gemm(dkeypre, weights->Wk, denc, nullptr, M, d.E, d.A, d.A, d.E, d.E, 1, 0, ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, 0, 0, prec, stream);
     if (rc != ASR_OK) return rc;
-    // slot partials -> d w_g, d W_proj, d b_g, d W_conv
-    const int nslots = d.B * lay.ntiles;
+    // slot partials -> d w_g, d W_proj, d b_g;  d W_conv from the saved dconv of every step
+    const int nslots = d.B * lay.nte;
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->wg, 0, d.A, 0, 0);
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A * d.Kn, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wproj, d.A, d.A * d.Kn, d.A, d.Kn);
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(1), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->bg, d.A * (1 + d.Kn), 1, 0, 0);
-    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.Kn * taps, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wconv,
-                       d.A * (1 + d.Kn) + 1, d.Kn * taps, 0, 0);
+    hipLaunchKernelGGL(wconv_grad_kernel, dim3(lay.nch, d.B), dim3(512), lay.lds_w, st, p.f, wslots);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.Kn * taps, 4)), dim3(256), 0, st, wslots, d.B * lay.nch, d.Kn * taps, grads->Wconv,
+                       0, d.Kn * taps, 0, 0);
     ASR_LAUNCH_CHECK("asr_att_decoder_bwd(tail)");
     return ASR_OK;
 }

@@ -100,7 +100,7 @@ class BeamDecoder(nn.Module):
         nmax = self.beam_size
         L = max(max_len, 1)
         d = F_hip._dec_dims(asr, nmax, Tp, L)
-        sd = F_hip._dec_state(d, dev)
+        sd = F_hip._dec_state(d, dev, save_conv=False)
         w = H.dec_weights_struct(F_hip._dec_tensors(asr, False), d.NL)
         s = H.dec_state_struct(sd)
         enc_rep = enc.expand(nmax, Tp, enc.shape[2]).contiguous()

@@ -256,9 +256,11 @@ def _dec_tensors(model, grads):
     }
 
 
-def _dec_state(d, dev):
+def _dec_state(d, dev, save_conv=True):
+    """save_conv: keep the location-convolution output of every step (B,L,Kn,Tp) for the backward pass."""
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     return {
+        'conv': f(d.B, d.L, d.Kn, d.Tp) if save_conv else None,
         'key': f(d.B, d.Tp, d.A), 'att': f(d.B, d.L, d.Tp), 'q': f(d.B, d.L, d.A), 'xin': f(d.B, d.L, d.Dd + d.E),
         'gates': f(d.B, d.L, d.NL, 4 * d.Dd), 'cs': f(d.B, d.L, d.NL, d.Dd), 'hs': f(d.B, d.L, d.NL, d.Dd),
         'logits': f(d.B, d.L, d.V), 'energy': f(d.B, d.Tp),

@@ -31,7 +31,7 @@ class DecWeights(ctypes.Structure):
 
 
 class DecState(ctypes.Structure):
-    _fields_ = [(n, _vp) for n in ('key', 'att', 'q', 'xin', 'gates', 'cs', 'hs', 'logits', 'energy', 'tokens')]
+    _fields_ = [(n, _vp) for n in ('key', 'att', 'q', 'xin', 'gates', 'cs', 'hs', 'logits', 'energy', 'conv', 'tokens')]
 
 
 _P = ctypes.POINTER
@@ -190,5 +190,6 @@ def dec_weights_struct(tensors, nl):
 def dec_state_struct(tensors):
     s = DecState()
     for n, _ in DecState._fields_:
-        setattr(s, n, tensors[n].data_ptr())
+        t = tensors.get(n)
+        setattr(s, n, t.data_ptr() if t is not None else None)
     return s

@@ -183,6 +183,7 @@ typedef struct {        /* forward outputs / saved activations, caller-allocated
     float* hs;          /* (B,L,NL,Dd) */
     float* logits;      /* (B,L,V)    att_output */
     float* energy;      /* (B,Tp)     scratch */
+    float* conv;        /* (B,L,Kn,Tp) location-convolution output per step, kept for backward; may be NULL for inference */
     int64_t* tokens;    /* (B,L)      input token of each step (<sos>=0 first) */
 } asr_dec_state_t;
 

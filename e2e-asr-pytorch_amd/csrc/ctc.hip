@@ -1,10 +1,12 @@
 // CTC loss (blank = 0, reduction 'mean', zero_infinity = False) forward + gradient in one launch —
 // stands in for torch.nn.CTCLoss as the reference calls it (bin/train_asr.py:135,237).
 //
-// One workgroup per utterance; the 2L+1 states of the extended label sequence are striped over the
-// threads, alpha_{t-1} lives in an LDS double buffer, the time loop is sequential with one barrier per
-// frame.  alpha is spilled to HBM (workspace, (B,T,2L+1) fp32) and re-read by the beta sweep, which
-// also forms the gradient.  All of it is fp32 log-space (log-sum-exp), whatever `prec` the model runs in.
+// Two launches.  (1) ctc_sweep_kernel, grid (B, 2): workgroup (b, 0) runs the alpha recursion forward in time, workgroup
+// (b, 1) the beta recursion backward, concurrently; one thread per state of the extended label sequence, the previous
+// frame's lattice column in an LDS double buffer, ONE barrier per frame, the log-probabilities of a chunk of frames
+// staged in LDS so that no global read sits on the per-frame critical path; both lattices are spilled to the workspace
+// (2 x (B,T,2L+1) fp32).  (2) ctc_grad_kernel, grid (ceil(T/FCH), B): gradient of every frame from alpha + beta,
+// fully parallel over frames.  All fp32 log-space (log-sum-exp), whatever `prec` the model runs in.
 //
 // Gradient convention = the one torch returns for log-softmax inputs: for t < input_len
 //   g[b,t,v] = gscale / (B * max(target_len_b,1)) * ( exp(lp[b,t,v]) - sum_{s: ext_s = v} exp(alpha+beta-lp+nll) )
@@ -22,13 +24,23 @@ struct CtcP {
     float* loss;            // scalar, += nll_b / (max(tl,1) * B)
     float* grad;            // (B,T,V)
     float* alpha;           // workspace (B,T,Smax)
+    float* beta;            // workspace (B,T,Smax)
     int B, T, V, L, Smax;
     float gscale;
 };
 
-__global__ __launch_bounds__(256) void ctc_loss_kernel(CtcP p) {
+// log(exp(a) + exp(b)) with one v_exp and one v_log; tolerates -inf on either side
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(1.f + __expf(-fabsf(a - b)));
+}
+
+constexpr int CTC_FCH = 8;        // frames per workgroup of the gradient kernel
+
+__global__ __launch_bounds__(1024) void ctc_sweep_kernel(CtcP p, int CF) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, back = blockIdx.y;
     const int tid = threadIdx.x, NTH = blockDim.x;
     const int V = p.V, T = p.T;
     int tl = (int)p.tgt_len[b];
@@ -36,100 +48,124 @@ __global__ __launch_bounds__(256) void ctc_loss_kernel(CtcP p) {
     const int S = 2 * tl + 1;
     int Tin = (int)p.in_len[b];
     Tin = max(0, min(Tin, T));
-
-    int* ext = reinterpret_cast<int*>(smem);                     // [Smax]
-    float* buf0 = reinterpret_cast<float*>(ext + p.Smax);         // [Smax]
-    float* buf1 = buf0 + p.Smax;                                  // [Smax]
-    float* acc = buf1 + p.Smax;                                   // [V]
-
+    int* ext = reinterpret_cast<int*>(smem);                     // [Smax + 2]
+    float* buf0 = reinterpret_cast<float*>(ext + p.Smax + 2) + 2;  // [-2 .. Smax+2) padded with -inf on both sides
+    float* buf1 = buf0 + p.Smax + 6;
+    float* s_lp = buf1 + p.Smax + 4;                              // [CF][V] chunk of log-probs
     const float* lp = p.lp + (long)b * T * V;
-    float* grad = p.grad + (long)b * T * V;
-    float* alpha = p.alpha + (long)b * T * p.Smax;
+    float* lat = (back ? p.beta : p.alpha) + (long)b * T * p.Smax;
 
-    for (int s = tid; s < S; s += NTH) ext[s] = (s & 1) ? (int)p.tgt[(long)b * p.L + (s >> 1)] : 0;
-    // zero the whole gradient slab of this utterance first (covers t >= Tin and the Tin == 0 case)
-    for (long i = tid; i < (long)T * V; i += NTH) grad[i] = 0.f;
+    for (int s = tid; s < p.Smax + 2; s += NTH) ext[s] = (s < S && (s & 1)) ? (int)p.tgt[(long)b * p.L + (s >> 1)] : 0;
+    for (int s = tid - 2; s < p.Smax + 2; s += NTH) { buf0[s] = -INFINITY; buf1[s] = -INFINITY; }
     __syncthreads();
-
     if (Tin == 0) {
-        // no frames: only the empty target is feasible
-        if (tid == 0) {
-            float n = (tl == 0) ? 0.f : INFINITY;
+        if (!back && tid == 0) {                 // no frames: only the empty target is feasible
+            const float n = (tl == 0) ? 0.f : INFINITY;
             p.nll[b] = n;
             atomicAdd(p.loss, n / (float)(max(tl, 1) * p.B));
         }
         return;
     }
-
-    // ---- alpha sweep ---------------------------------------------------------------------------
+    // per-state constants: label, and whether the skip transition (s-2 -> s forward, s+2 -> s backward) is allowed
+    const int s = tid;
+    const bool sok = s < S;
+    const int e = sok ? ext[s] : 0;
+    bool skip = false;
+    if (sok && !back) skip = (s >= 2) && e != 0 && e != ext[s - 2];
+    if (sok && back) skip = (s + 2 < S) && ext[s + 2] != 0 && ext[s + 2] != e;
     float* prev = buf0;
     float* cur = buf1;
-    for (int s = tid; s < S; s += NTH) {
-        float a = -INFINITY;
-        if (s == 0) a = lp[0];
-        else if (s == 1) a = lp[ext[1]];
-        prev[s] = a;
-        alpha[s] = a;
-    }
-    __syncthreads();
-    for (int t = 1; t < Tin; ++t) {
-        const float* lpt = lp + (long)t * V;
-        for (int s = tid; s < S; s += NTH) {
-            const int e = ext[s];
-            float a = prev[s];
-            if (s >= 1) a = logaddexpf_(a, prev[s - 1]);
-            if (s >= 2 && e != 0 && e != ext[s - 2]) a = logaddexpf_(a, prev[s - 2]);
-            a += lpt[e];
-            cur[s] = a;
-            alpha[(long)t * p.Smax + s] = a;
-        }
+    for (int c0 = 0; c0 < Tin; c0 += CF) {
+        // frames of this chunk in processing order: forward t = c0 + i, backward t = Tin-1 - (c0 + i)
+        const int nf = min(CF, Tin - c0);
+        const int tlo = back ? Tin - c0 - nf : c0;
         __syncthreads();
-        float* tmp = prev; prev = cur; cur = tmp;
-    }
-    float ll = prev[S - 1];
-    if (S > 1) ll = logaddexpf_(ll, prev[S - 2]);
-    const float nll = -ll;
-    __syncthreads();
-    if (tid == 0) {
-        p.nll[b] = nll;
-        atomicAdd(p.loss, nll / (float)(max(tl, 1) * p.B));
-    }
-    const float scale = p.gscale / (float)(max(tl, 1) * p.B);
-
-    // ---- beta sweep + gradient -----------------------------------------------------------------
-    // prev <- beta_{t+1}
-    for (int t = Tin - 1; t >= 0; --t) {
-        const float* lpt = lp + (long)t * V;
-        for (int v = tid; v < V; v += NTH) acc[v] = 0.f;
+        for (int i = tid; i < nf * V; i += NTH) s_lp[i] = lp[(long)tlo * V + i];
         __syncthreads();
-        for (int s = tid; s < S; s += NTH) {
-            const int e = ext[s];
-            float bt;
-            if (t == Tin - 1) {
-                bt = (s == S - 1 || s == S - 2) ? 0.f : -INFINITY;
+        for (int i = 0; i < nf; ++i) {
+            const int t = back ? Tin - 1 - (c0 + i) : c0 + i;
+            const float lpe = s_lp[(t - tlo) * V + e];
+            float a;
+            if (c0 + i == 0) {
+                if (!back) a = (s == 0 || s == 1) ? lpe : -INFINITY;          // alpha_0: states 0 and 1 (ext[1] read is safe: ext is padded)
+                else       a = (s == S - 1 || s == S - 2) ? lpe : -INFINITY;  // beta_{Tin-1}
             } else {
-                bt = prev[s];
-                if (s + 1 < S) bt = logaddexpf_(bt, prev[s + 1]);
-                if (s + 2 < S && ext[s + 2] != 0 && ext[s + 2] != e) bt = logaddexpf_(bt, prev[s + 2]);
+                const int d1 = back ? 1 : -1;
+                a = lse2(prev[s], prev[s + d1]);
+                if (skip) a = lse2(a, prev[s + 2 * d1]);
+                a += lpe;
             }
-            const float lpe = lpt[e];
-            bt += lpe;
-            cur[s] = bt;
-            // occupancy term: exp(alpha + beta - lp + nll); NaN when nll = +inf (infeasible), as in the reference
-            const float term = expf(alpha[(long)t * p.Smax + s] + bt - lpe + nll);
-            atomicAdd(&acc[e], term);
+            if (sok) { cur[s] = a; lat[(long)t * p.Smax + s] = a; }
+            __syncthreads();
+            float* tmp = prev; prev = cur; cur = tmp;
         }
-        __syncthreads();
-        for (int v = tid; v < V; v += NTH) grad[(long)t * V + v] = scale * (expf(lpt[v]) - acc[v]);
-        float* tmp = prev; prev = cur; cur = tmp;
-        __syncthreads();
+    }
+    if (!back && tid == 0) {
+        float ll = prev[S - 1];
+        if (S > 1) ll = lse2(ll, prev[S - 2]);
+        p.nll[b] = -ll;
+        atomicAdd(p.loss, -ll / (float)(max(tl, 1) * p.B));
+    }
+}
+
+// gradient of CTC_FCH frames of one utterance: one thread per state, class sums through LDS (labels by atomics with the
+// multiplicity of the label in the target as contention, blank by a wave reduction)
+__global__ __launch_bounds__(1024) void ctc_grad_kernel(CtcP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.y, t0 = blockIdx.x * CTC_FCH;
+    const int tid = threadIdx.x, NTH = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = NTH >> 6;
+    const int V = p.V, T = p.T;
+    int tl = (int)p.tgt_len[b];
+    tl = max(0, min(tl, p.L));
+    const int S = 2 * tl + 1;
+    int Tin = (int)p.in_len[b];
+    Tin = max(0, min(Tin, T));
+    float* acc = reinterpret_cast<float*>(smem);          // [FCH][V]
+    float* blk = acc + CTC_FCH * V;                       // [FCH][nwave] blank partial sums
+    const float* lp = p.lp + (long)b * T * V;
+    float* grad = p.grad + (long)b * T * V;
+    for (int i = tid; i < CTC_FCH * V; i += NTH) acc[i] = 0.f;
+    const int s = tid;
+    const bool sok = s < S;
+    const int e = (sok && (s & 1)) ? (int)p.tgt[(long)b * p.L + (s >> 1)] : 0;
+    const float nll = p.nll[b];
+    const float scale = p.gscale / (float)(max(tl, 1) * p.B);
+    float occ[CTC_FCH];
+#pragma unroll
+    for (int f = 0; f < CTC_FCH; ++f) {
+        const int t = t0 + f;
+        occ[f] = 0.f;
+        if (sok && t < Tin) {
+            const long li = ((long)b * T + t) * p.Smax + s;
+            // occupancy: exp(alpha + beta - lp + nll); NaN when nll = +inf (infeasible), as in the reference
+            occ[f] = expf(p.alpha[li] + p.beta[li] - lp[(long)t * V + e] + nll);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < CTC_FCH; ++f) {
+        if (sok && (s & 1) && t0 + f < Tin) atomicAdd(&acc[f * V + e], occ[f]);
+        const float bsum = wave_sum((sok && !(s & 1)) ? occ[f] : 0.f);
+        if (lane == 0) blk[f * nwave + wave] = bsum;
+    }
+    __syncthreads();
+    for (int i = tid; i < CTC_FCH * V; i += NTH) {
+        const int f = i / V, v = i - f * V, t = t0 + f;
+        if (t >= T) continue;
+        float g = 0.f;
+        if (t < Tin) {
+            float a = acc[i];
+            if (v == 0) for (int w = 0; w < nwave; ++w) a += blk[f * nwave + w];
+            g = scale * (expf(lp[(long)t * V + v]) - a);
+        }
+        grad[(long)t * V + v] = g;
     }
 }
 
 }  // namespace
 
 extern "C" size_t asr_ctc_loss_workspace_bytes(int B, int T, int L) {
-    return (size_t)B * T * (2 * (size_t)L + 1) * sizeof(float);
+    return 2 * (size_t)B * T * (2 * (size_t)L + 1) * sizeof(float);
 }
 
 extern "C" int asr_ctc_loss(const float* logp, const int64_t* targets, const int64_t* input_len, const int64_t* target_len,
@@ -138,12 +174,22 @@ extern "C" int asr_ctc_loss(const float* logp, const int64_t* targets, const int
     ASR_REQUIRE(logp && targets && input_len && target_len && nll && loss && grad && workspace, ASR_E_ARG, "asr_ctc_loss: null pointer");
     ASR_REQUIRE(B > 0 && T > 0 && V > 1 && L > 0, ASR_E_ARG, "asr_ctc_loss: bad dims");
     ASR_REQUIRE(workspace_bytes >= asr_ctc_loss_workspace_bytes(B, T, L), ASR_E_ARG, "asr_ctc_loss: workspace too small");
-    CtcP p{logp, targets, input_len, target_len, nll, loss, grad, (float*)workspace, B, T, V, L, 2 * L + 1, gscale};
-    size_t lds = (size_t)p.Smax * 12 + (size_t)V * 4;
-    ASR_REQUIRE(lds <= 64 * 1024, ASR_E_UNSUPPORTED, "asr_ctc_loss: 2L+1=%d states and V=%d classes exceed the LDS budget", p.Smax, V);
+    const int Smax = 2 * L + 1;
+    float* wsf = (float*)workspace;
+    CtcP p{logp, targets, input_len, target_len, nll, loss, grad, wsf, wsf + (size_t)B * T * Smax, B, T, V, L, Smax, gscale};
+    ASR_REQUIRE(Smax <= 1024, ASR_E_UNSUPPORTED, "asr_ctc_loss: 2L+1=%d states exceed one workgroup", Smax);
+    const int nthr = ((Smax + 63) / 64) * 64;
+    // frames of log-probs staged per chunk: as many as fit beside the lattice buffers in 60 KB
+    const size_t fixed = (size_t)(Smax + 2) * 4 + 2 * (size_t)(Smax + 6) * 4 + 16;
+    int CF = (int)((60 * 1024 - fixed) / ((size_t)V * 4));
+    ASR_REQUIRE(CF >= 1, ASR_E_UNSUPPORTED, "asr_ctc_loss: 2L+1=%d states and V=%d classes exceed the LDS budget", Smax, V);
+    if (CF > T) CF = T;
+    const size_t lds_s = fixed + (size_t)CF * V * 4;
+    const size_t lds_g = (size_t)CTC_FCH * (V + nthr / 64) * 4;
     hipStream_t st = (hipStream_t)stream;
     hipMemsetAsync(loss, 0, sizeof(float), st);
-    hipLaunchKernelGGL(ctc_loss_kernel, dim3(B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(ctc_sweep_kernel, dim3(B, 2), dim3(nthr), lds_s, st, p, CF);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(cdiv(T, CTC_FCH), B), dim3(nthr), lds_g, st, p);
     ASR_LAUNCH_CHECK("asr_ctc_loss");
     return ASR_OK;
 }

@@ -153,10 +153,17 @@ __device__ __forceinline__ bf16x8 frag_bf16(const void* lds, int row0, int ks) {
         constexpr int LD = TileLayout<true, true>::LD;
         return *reinterpret_cast<const bf16x8*>(s + row * LD + k);
     } else {
+        // [k][row] image (the operand's memory order): two hardware-transposed reads.  Per 16-lane group g the
+        // instruction takes a block of 4 k-rows x 16 rows; lane 4q+p supplies the address of (k-row q, rows 4p..4p+3)
+        // and lane i receives row i of the four k-rows, i.e. k = 8g+q for its own MFMA row.  EXEC is all ones here.
         constexpr int LD = TileLayout<true, false>::LD;
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+        const __bf16* a0 = s + (ks * 32 + 8 * g + q) * LD + row0 + 4 * pp;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * LD));
         bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = s[(k + j) * LD + row];
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return v;
     }
 }

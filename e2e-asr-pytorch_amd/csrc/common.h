@@ -112,6 +112,50 @@ __device__ __forceinline__ bf16x8 load8_bf16(const float* p, int k, int kend, bo
     return v;
 }
 
+// Same as dot_rows for the concatenation of two reduction segments ([a1 | a2] . [b1 | b2], segment 2 optional):
+// the k-steps of both segments form one sequence, so ONE batch of U steps per wave (one memory round trip)
+// covers e.g. the input and the recurrent product of an LSTM cell.
+template <bool BF16, int U>
+__device__ __forceinline__ f32x4 dot_rows_cat(const float* a1, const float* b1, int K1, bool vec1,
+                                              const float* a2, const float* b2, int K2, bool vec2,
+                                              bool aok, bool bok, int ks_beg, int ks_stride, f32x4 acc) {
+    const int q = (threadIdx.x & 63) >> 4;
+    if (BF16) {
+        const int n1 = (K1 + 31) >> 5, n2 = (K2 + 31) >> 5, nks = n1 + n2;
+        for (int ks0 = ks_beg; ks0 < nks; ks0 += U * ks_stride) {
+            bf16x8 a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ks = ks0 + u * ks_stride;
+                const bool in = ks < nks, s2 = ks >= n1;
+                const int k = (s2 ? ks - n1 : ks) * 32 + 8 * q;
+                a[u] = load8_bf16(s2 ? a2 : a1, k, s2 ? K2 : K1, aok && in, s2 ? vec2 : vec1);
+                b[u] = load8_bf16(s2 ? b2 : b1, k, s2 ? K2 : K1, bok && in, s2 ? vec2 : vec1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = mma16(a[u], b[u], acc);
+        }
+    } else {
+        const int n1 = (K1 + 3) >> 2, n2 = (K2 + 3) >> 2, nks = n1 + n2;
+        constexpr int UF = 4 * U;
+        for (int ks0 = ks_beg; ks0 < nks; ks0 += UF * ks_stride) {
+            float a[UF], b[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int ks = ks0 + u * ks_stride;
+                const bool in = ks < nks, s2 = ks >= n1;
+                const int k = (s2 ? ks - n1 : ks) * 4 + q;
+                const int K = s2 ? K2 : K1;
+                a[u] = (aok && in && k < K) ? (s2 ? a2 : a1)[k] : 0.f;
+                b[u] = (bok && in && k < K) ? (s2 ? b2 : b1)[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) acc = mma16(a[u], b[u], acc);
+        }
+    }
+    return acc;
+}
+
 // acc += A(16 x K) * B(K x 16) where lane (l&15) addresses row `arow` of A and column-row `brow` of B,
 // both K-contiguous in memory; k-steps ks_beg, ks_beg+ks_stride, ...  The loads of U k-steps are issued
 // together before the MFMAs so that one memory round trip covers U steps (these kernels are latency-bound).

@@ -349,35 +349,38 @@ __global__ __launch_bounds__(256) void dec_cell_fwd_kernel(DecP p, int t, int l)
         const bool rok = ab < d.B;
         const long rowi = (long)(rok ? ab : 0) * d.L + t;
         const float* xrow = (l == 0) ? p.s.xin + rowi * XW : p.s.hs + rowi * SW + (long)(l - 1) * d.Dd;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = dot_rows<BF16>(xrow, rok, wih, jok, Kx, wave, 4, (Kx % 4) == 0 && (d.Dd % 4) == 0, acc);
-        if (t > 0) {
-            const float* hrow = p.s.hs + (rowi - 1) * SW + (long)l * d.Dd;
-            acc = dot_rows<BF16>(hrow, rok, whh, jok, d.Dd, wave, 4, (d.Dd % 4) == 0, acc);
+        const float* hrow = p.s.hs + (rowi - (t > 0 ? 1 : 0)) * SW + (long)l * d.Dd;
+        // the epilogue's operands (biases, previous cell state) are requested together with the contraction's
+        const int erow = tid >> 2, ejj = tid & 3;
+        const int eb = m0 + erow, eju = blockIdx.x * 4 + ejj;
+        const bool eok = tid < 64 && eb < d.B && eju < d.Dd;
+        const long eri = (long)(eok ? eb : 0) * d.L + t;
+        float bsum[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f;
+        if (eok) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) bsum[gg] = p.w.bih[l][gg * d.Dd + eju] + p.w.bhh[l][gg * d.Dd + eju];
+            if (t > 0) cp = p.s.cs[(eri - 1) * SW + (long)l * d.Dd + eju];
         }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = dot_rows_cat<BF16, 10>(xrow, wih, Kx, (Kx % 4) == 0 && (d.Dd % 4) == 0, hrow, whh, (t > 0) ? d.Dd : 0, (d.Dd % 4) == 0,
+                                     rok, jok, wave, 4, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
         __syncthreads();
-        if (tid < 64) {
+        if (eok) {
             // thread (row, unit): gathers its four gate columns
-            const int row = tid >> 2, jj = tid & 3;
-            const int b = m0 + row, ju = blockIdx.x * 4 + jj;
-            if (b < d.B && ju < d.Dd) {
-                float pre[4];
+            float pre[4];
 #pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const int c = row * 16 + gg * 4 + jj;
-                    pre[gg] = red[0][c] + red[1][c] + red[2][c] + red[3][c] + p.w.bih[l][gg * d.Dd + ju] + p.w.bhh[l][gg * d.Dd + ju];
-                }
-                const float ai = sigmoidf_(pre[0]), af = sigmoidf_(pre[1]), ag = tanhf(pre[2]), ao = sigmoidf_(pre[3]);
-                const long ri = (long)b * d.L + t;
-                float* go = p.s.gates + (ri * d.NL + l) * 4 * d.Dd;
-                go[ju] = ai; go[d.Dd + ju] = af; go[2 * d.Dd + ju] = ag; go[3 * d.Dd + ju] = ao;
-                const float cp = (t > 0) ? p.s.cs[(ri - 1) * SW + (long)l * d.Dd + ju] : 0.f;
-                const float cn = af * cp + ai * ag;
-                p.s.cs[ri * SW + (long)l * d.Dd + ju] = cn;
-                p.s.hs[ri * SW + (long)l * d.Dd + ju] = ao * tanhf(cn);
+            for (int gg = 0; gg < 4; ++gg) {
+                const int c = erow * 16 + gg * 4 + ejj;
+                pre[gg] = red[0][c] + red[1][c] + red[2][c] + red[3][c] + bsum[gg];
             }
+            const float ai = sigmoidf_(pre[0]), af = sigmoidf_(pre[1]), ag = tanhf(pre[2]), ao = sigmoidf_(pre[3]);
+            float* go = p.s.gates + (eri * d.NL + l) * 4 * d.Dd;
+            go[eju] = ai; go[d.Dd + eju] = af; go[2 * d.Dd + eju] = ag; go[3 * d.Dd + eju] = ao;
+            const float cn = af * cp + ai * ag;
+            p.s.cs[eri * SW + (long)l * d.Dd + eju] = cn;
+            p.s.hs[eri * SW + (long)l * d.Dd + eju] = ao * tanhf(cn);
         }
         __syncthreads();
     }
@@ -482,23 +485,28 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_mm_kernel(DecB p, int t, int
         const int ab = m0 + n;
         const bool rok = ab < d.B;
         const float* grow = p.f.s.gates + ((((long)(rok ? ab : 0) * d.L + t) * d.NL) + l) * K;
+        // accumulate targets are read before the contraction (one round trip for everything)
+        const int row = tid >> 4, col = tid & 15;
+        const int b = m0 + row, c = c0 + col;
+        const bool ook = b < d.B && c < Kx + d.Dd;
+        const long ri = (long)(ook ? b : 0) * d.L + t;
+        float* dst = nullptr;
+        bool add = false;
+        if (ook) {
+            if (c < Kx) {
+                if (l == 0) dst = p.dxin + ri * XW + c;
+                else { dst = p.dhs + ri * SW + (long)(l - 1) * d.Dd + c; add = true; }
+            } else if (t > 0) {
+                dst = p.dhs + (ri - 1) * SW + (long)l * d.Dd + (c - Kx); add = true;
+            }
+        }
+        const float oldv = (dst && add) ? *dst : 0.f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = dot_rows<BF16>(grow, rok, wrow, cok, K, wave, 4, true, acc);
+        acc = dot_rows<BF16, 10>(grow, rok, wrow, cok, K, wave, 4, true, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
         __syncthreads();
-        const int row = tid >> 4, col = tid & 15;
-        const int b = m0 + row, c = c0 + col;
-        if (b < d.B && c < Kx + d.Dd) {
-            const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-            const long ri = (long)b * d.L + t;
-            if (c < Kx) {
-                if (l == 0) p.dxin[ri * XW + c] = v;
-                else p.dhs[ri * SW + (long)(l - 1) * d.Dd + c] += v;
-            } else if (t > 0) {
-                p.dhs[(ri - 1) * SW + (long)l * d.Dd + (c - Kx)] += v;
-            }
-        }
+        if (dst) *dst = oldv + red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
         __syncthreads();
     }
 }

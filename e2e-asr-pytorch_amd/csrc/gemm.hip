@@ -9,6 +9,7 @@
 // f32 accumulate) or exact f32-input MFMA (parity mode).
 // Tile: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave 4x4 tiles of 16x16.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,6 +28,9 @@ struct GemmP {
     // implicit 3x3 convolution over a channel-last image (rows = (b,t,f), cT x cF pixels, cC channels):
     // the conv operand's reduction/column index k = tap*cC + ci addresses pixel (t+dt, f+df), zero outside.
     int convA, convB, cT, cF, cC;
+    // XCD-aware tile order (see gemm_kernel): column tiles, row tiles, z slices, rows per XCD band, column group width
+    int nx, ny, nz, rpb, gx, ngx, plain_order;
+    int fastA, fastB;      // operand qualifies for fetch_tile_fast
 };
 
 // source row offset and validity of tap (dt,df) for pixel row m
@@ -120,6 +124,40 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ base, long 
     }
 }
 
+// Fast variant of fetch_tile for the common case (no convolution, 16-byte aligned rows, the contiguous extent a
+// multiple of 4): every load is issued unconditionally from a CLAMPED address and zeroed afterwards by a select.
+// (Loads under lane-dependent conditions are compiled into a branch + `s_waitcnt vmcnt(0)` each: the 8 loads of a tile
+// became 8 serialized round trips per k-step, which - not bandwidth, not the MFMA - set the speed of this kernel.)
+template <bool KC>
+__device__ __forceinline__ void fetch_tile_fast(const float* __restrict__ base, long ld, int row0, int nrows,
+                                                int k0, int kend, int seqT, int shift, float4 (&r)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bool ok;
+        const float* ptr;
+        if (KC) {
+            const int row = row0 + (tid >> 3) + 32 * q;
+            const int k = k0 + (tid & 7) * 4;
+            ok = row < nrows && k < kend;                       // kend % 4 == 0: a float4 is all in or all out
+            ptr = base + (long)min(row, nrows - 1) * ld + min(k, kend - 4);
+        } else {
+            const int k = k0 + (tid >> 5) + 8 * q;
+            const int row = row0 + (tid & 31) * 4;
+            ok = k < kend && row < nrows;                       // nrows % 4 == 0
+            long ksrc = min(k, kend - 1);
+            if (seqT > 0) {
+                const int t = k % seqT + shift;
+                ok = ok && (t >= 0) && (t < seqT);
+                ksrc = min(max(ksrc + shift, 0L), (long)kend - 1);
+            }
+            ptr = base + ksrc * ld + min(row, nrows - 4);
+        }
+        const float4 v = *reinterpret_cast<const float4*>(ptr);
+        r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 template <bool BF16, bool KC>
 __device__ __forceinline__ void stash_tile(void* lds, const float4 (&r)[4]) {
     const int tid = threadIdx.x;
@@ -185,14 +223,36 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     void* As = smem;
     void* Bs = smem + A_BYTES;
 
-    const int zb = blockIdx.z / p.splits;
-    const int zs = blockIdx.z % p.splits;
+    // Tile order.  Workgroup i of a launch runs on XCD i % 8 (round-robin dispatch) and each XCD has its own 4 MB L2;
+    // a CU takes in only ~10 B/clk from beyond its L2 but 64 B/clk from it, and at 128 x 128 tiles fed from fp32
+    // operands that fabric rate, not the MFMA, sets the speed.  So each XCD gets a contiguous band of (z, row-tile)
+    // pairs, walks it column group by column group (gx column tiles whose B operand slices fit the L2 together), and
+    // inside a group row by row with the column fastest: the A slice of a row is fetched once per group and the
+    // group's B slices stay resident for the whole band.  (Speed only: any placement gives the same result.)
+    int bx, by, bz;
+    if (p.plain_order) {
+        const int id = blockIdx.x;
+        bx = id % p.nx; by = (id / p.nx) % p.ny; bz = id / (p.nx * p.ny);
+        if (bz >= p.nz) return;
+    } else {
+        const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+        const int per_g = p.rpb * p.gx;
+        const int xg = local / per_g, rr = local - xg * per_g;
+        const int yb = rr / p.gx, xi = rr - yb * p.gx;
+        const int rrow = xcd * p.rpb + yb;
+        bx = xg * p.gx + xi;
+        if (bx >= p.nx || rrow >= p.ny * p.nz) return;
+        bz = rrow / p.ny;
+        by = rrow - bz * p.ny;
+    }
+    const int zb = bz / p.splits;
+    const int zs = bz % p.splits;
     const float* A = p.A + (long)zb * p.sA;
     const float* B = p.B + (long)zb * p.sB;
     float* C = p.C + (long)zb * p.sC;
 
-    const int i0 = blockIdx.y * BM;
-    const int j0 = blockIdx.x * BN;
+    const int i0 = by * BM;
+    const int j0 = bx * BN;
 
     // reduction range of this split (multiple of BK)
     const int ktiles = (p.K + BK - 1) / BK;
@@ -212,17 +272,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 ra[4], rb[4];
-    fetch_tile<AKC>(A, p.lda, i0, p.M, kt0 * BK, p.K, p.vecA, 0, 0, ra, p.convA, p.cT, p.cF, p.cC);
-    fetch_tile<BKC>(B, p.ldb, j0, p.N, kt0 * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb, p.convB, p.cT, p.cF, p.cC);
+    auto fetch = [&](int kk) {
+        if (p.fastA) fetch_tile_fast<AKC>(A, p.lda, i0, p.M, kk, p.K, 0, 0, ra);
+        else fetch_tile<AKC>(A, p.lda, i0, p.M, kk, p.K, p.vecA, 0, 0, ra, p.convA, p.cT, p.cF, p.cC);
+        if (p.fastB) fetch_tile_fast<BKC>(B, p.ldb, j0, p.N, kk, p.K, BKC ? 0 : p.seqT, p.bshift, rb);
+        else fetch_tile<BKC>(B, p.ldb, j0, p.N, kk, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb, p.convB, p.cT, p.cF, p.cC);
+    };
+    fetch(kt0 * BK);
 
     for (int kt = kt0; kt < kt1; ++kt) {
         stash_tile<BF16, AKC>(As, ra);
         stash_tile<BF16, BKC>(Bs, rb);
         __syncthreads();
-        if (kt + 1 < kt1) {
-            fetch_tile<AKC>(A, p.lda, i0, p.M, (kt + 1) * BK, p.K, p.vecA, 0, 0, ra, p.convA, p.cT, p.cF, p.cC);
-            fetch_tile<BKC>(B, p.ldb, j0, p.N, (kt + 1) * BK, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb, p.convB, p.cT, p.cF, p.cC);
-        }
+        if (kt + 1 < kt1) fetch((kt + 1) * BK);
         if (BF16) {
             bf16x8 fa[4], fb[4];
 #pragma unroll
@@ -279,8 +341,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 }
 
 template <bool BF16>
-int launch_gemm(const GemmP& p, int a_kc, int b_kc, hipStream_t st) {
-    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.batch * p.splits);
+int launch_gemm(const GemmP& p0, int a_kc, int b_kc, hipStream_t st) {
+    GemmP p = p0;
+    p.nx = cdiv(p.N, BN); p.ny = cdiv(p.M, BM); p.nz = p.batch * p.splits;
+    p.rpb = cdiv((long)p.ny * p.nz, 8);
+    const long b_slice = (long)BN * cdiv(p.K, p.splits) * (long)sizeof(float);      // B operand bytes of one column tile
+    long gx = (5L << 19) / (b_slice > 0 ? b_slice : 1);                              // ~2.5 MB of B slices per group
+    p.gx = (int)(gx < 1 ? 1 : (gx > p.nx ? p.nx : gx));
+    p.ngx = cdiv(p.nx, p.gx);
+    // fast loader: no convolution operand, 16-byte aligned rows, contiguous extent a multiple of 4 and at least one float4
+    p.fastA = (!p.convA && p.vecA && (a_kc ? (p.K % 4 == 0 && p.K >= 4) : (p.M % 4 == 0 && p.M >= 4))) ? 1 : 0;
+    p.fastB = (!p.convB && p.vecB && (b_kc ? (p.K % 4 == 0 && p.K >= 4) : (p.N % 4 == 0 && p.N >= 4))) ? 1 : 0;
+    static int plain = -1;
+    if (plain < 0) { const char* e = getenv("ASR_GEMM_PLAIN_ORDER"); plain = (e && e[0] == '1') ? 1 : 0; }
+    // measured (tools/bench_gemm.py): the banded order wins when a row of tiles is short (N <= 1024: projection and input-
+    // gradient shapes, 1.15-1.2x) and loses for wide outputs and split reductions, which keep the natural order
+    p.plain_order = (plain || p.nz > 1 || p.nx > 8) ? 1 : 0;
+    const long nblk = p.plain_order ? (long)p.nx * p.ny * p.nz : 8L * p.rpb * p.ngx * p.gx;
+    ASR_REQUIRE(nblk < (1L << 31), ASR_E_UNSUPPORTED, "asr_gemm: %ld tiles", nblk);
+    dim3 grid((unsigned)nblk);
     dim3 block(NT);
     if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_kernel<BF16, true, true>), grid, block, 0, st, p);
     else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_kernel<BF16, true, false>), grid, block, 0, st, p);

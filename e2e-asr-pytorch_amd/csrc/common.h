@@ -97,24 +97,38 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32
 }
 
 // ---- small-M MFMA row dot products (recurrent / per-step matvecs) ------------------------------
-// 8 consecutive fp32 -> bf16x8 (guarded against the end of the row)
-__device__ __forceinline__ bf16x8 load8_bf16(const float* p, int k, int kend, bool ok, bool vec) {
+// These kernels are latency-bound, so the loads of U k-steps must be in flight TOGETHER.  A load under a lane-dependent
+// condition is compiled into a branch plus its own `s_waitcnt vmcnt(0)` (U serialized round trips), and so is a load
+// whose value is converted in the same basic block behind a uniform branch; therefore: one uniform branch on `vec`
+// around the whole batch, every load unconditional from a clamped address, zeroing by selects after the batch.
+struct Raw8 { float4 lo, hi; };
+// rows 16-byte aligned, kend % 4 == 0
+__device__ __forceinline__ Raw8 load8_raw(const float* p, int k, int kend) {
+    Raw8 r;
+    r.lo = *reinterpret_cast<const float4*>(p + max(min(k, kend - 4), 0));
+    r.hi = *reinterpret_cast<const float4*>(p + max(min(k + 4, kend - 4), 0));
+    return r;
+}
+__device__ __forceinline__ bf16x8 cvt8(const Raw8& r, int k, int kend, bool ok) {
+    const bool oa = ok && k < kend, ob = ok && k + 4 < kend;
     bf16x8 v;
-    if (ok && vec && k + 7 < kend) {
-        float4 a = *reinterpret_cast<const float4*>(p + k);
-        float4 b = *reinterpret_cast<const float4*>(p + k + 4);
-        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-        v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
-    } else {
+    v[0] = (__bf16)(oa ? r.lo.x : 0.f); v[1] = (__bf16)(oa ? r.lo.y : 0.f); v[2] = (__bf16)(oa ? r.lo.z : 0.f); v[3] = (__bf16)(oa ? r.lo.w : 0.f);
+    v[4] = (__bf16)(ob ? r.hi.x : 0.f); v[5] = (__bf16)(ob ? r.hi.y : 0.f); v[6] = (__bf16)(ob ? r.hi.z : 0.f); v[7] = (__bf16)(ob ? r.hi.w : 0.f);
+    return v;
+}
+// generic (unaligned / ragged) rows: scalar loads from clamped addresses
+__device__ __forceinline__ bf16x8 load8_slow(const float* p, int k, int kend, bool ok) {
+    bf16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (__bf16)((ok && k + j < kend) ? p[k + j] : 0.f);
+    for (int j = 0; j < 8; ++j) {
+        const float x = p[max(min(k + j, kend - 1), 0)];
+        v[j] = (__bf16)((ok && k + j < kend) ? x : 0.f);
     }
     return v;
 }
 
-// Same as dot_rows for the concatenation of two reduction segments ([a1 | a2] . [b1 | b2], segment 2 optional):
-// the k-steps of both segments form one sequence, so ONE batch of U steps per wave (one memory round trip)
-// covers e.g. the input and the recurrent product of an LSTM cell.
+// acc += [a1 | a2] . [b1 | b2] over the k-steps ks_beg, ks_beg + ks_stride, ... of the concatenated reduction
+// (segment 2 optional: K2 = 0).  Lane (l&15) addresses row `a*` of A and column-row `b*` of B, both K-contiguous.
 template <bool BF16, int U>
 __device__ __forceinline__ f32x4 dot_rows_cat(const float* a1, const float* b1, int K1, bool vec1,
                                               const float* a2, const float* b2, int K2, bool vec2,
@@ -122,18 +136,39 @@ __device__ __forceinline__ f32x4 dot_rows_cat(const float* a1, const float* b1, 
     const int q = (threadIdx.x & 63) >> 4;
     if (BF16) {
         const int n1 = (K1 + 31) >> 5, n2 = (K2 + 31) >> 5, nks = n1 + n2;
-        for (int ks0 = ks_beg; ks0 < nks; ks0 += U * ks_stride) {
-            bf16x8 a[U], b[U];
+        if (vec1 && (vec2 || K2 == 0)) {
+            for (int ks0 = ks_beg; ks0 < nks; ks0 += U * ks_stride) {
+                Raw8 ra[U], rb[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ks = ks0 + u * ks_stride;
-                const bool in = ks < nks, s2 = ks >= n1;
-                const int k = (s2 ? ks - n1 : ks) * 32 + 8 * q;
-                a[u] = load8_bf16(s2 ? a2 : a1, k, s2 ? K2 : K1, aok && in, s2 ? vec2 : vec1);
-                b[u] = load8_bf16(s2 ? b2 : b1, k, s2 ? K2 : K1, bok && in, s2 ? vec2 : vec1);
+                for (int u = 0; u < U; ++u) {
+                    const int ks = ks0 + u * ks_stride;
+                    const bool s2 = ks >= n1 && K2 > 0;
+                    const int k = (s2 ? ks - n1 : min(ks, n1 - 1)) * 32 + 8 * q;
+                    ra[u] = load8_raw(s2 ? a2 : a1, k, s2 ? K2 : K1);
+                    rb[u] = load8_raw(s2 ? b2 : b1, k, s2 ? K2 : K1);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ks = ks0 + u * ks_stride;
+                    const bool in = ks < nks, s2 = ks >= n1 && K2 > 0;
+                    const int k = (s2 ? ks - n1 : min(ks, n1 - 1)) * 32 + 8 * q;
+                    acc = mma16(cvt8(ra[u], k, s2 ? K2 : K1, aok && in), cvt8(rb[u], k, s2 ? K2 : K1, bok && in), acc);
+                }
             }
+        } else {
+            for (int ks0 = ks_beg; ks0 < nks; ks0 += U * ks_stride) {
+                bf16x8 a[U], b[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc = mma16(a[u], b[u], acc);
+                for (int u = 0; u < U; ++u) {
+                    const int ks = ks0 + u * ks_stride;
+                    const bool in = ks < nks, s2 = ks >= n1 && K2 > 0;
+                    const int k = (s2 ? ks - n1 : min(ks, n1 - 1)) * 32 + 8 * q;
+                    a[u] = load8_slow(s2 ? a2 : a1, k, s2 ? K2 : K1, aok && in);
+                    b[u] = load8_slow(s2 ? b2 : b1, k, s2 ? K2 : K1, bok && in);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc = mma16(a[u], b[u], acc);
+            }
         }
     } else {
         const int n1 = (K1 + 3) >> 2, n2 = (K2 + 3) >> 2, nks = n1 + n2;
@@ -143,11 +178,12 @@ __device__ __forceinline__ f32x4 dot_rows_cat(const float* a1, const float* b1, 
 #pragma unroll
             for (int u = 0; u < UF; ++u) {
                 const int ks = ks0 + u * ks_stride;
-                const bool in = ks < nks, s2 = ks >= n1;
-                const int k = (s2 ? ks - n1 : ks) * 4 + q;
+                const bool in = ks < nks, s2 = ks >= n1 && K2 > 0;
+                const int k = (s2 ? ks - n1 : min(ks, n1 - 1)) * 4 + q;
                 const int K = s2 ? K2 : K1;
-                a[u] = (aok && in && k < K) ? (s2 ? a2 : a1)[k] : 0.f;
-                b[u] = (bok && in && k < K) ? (s2 ? b2 : b1)[k] : 0.f;
+                const float av = (s2 ? a2 : a1)[max(min(k, K - 1), 0)], bv = (s2 ? b2 : b1)[max(min(k, K - 1), 0)];
+                a[u] = (aok && in && k < K) ? av : 0.f;
+                b[u] = (bok && in && k < K) ? bv : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < UF; ++u) acc = mma16(a[u], b[u], acc);
@@ -156,42 +192,9 @@ __device__ __forceinline__ f32x4 dot_rows_cat(const float* a1, const float* b1, 
     return acc;
 }
 
-// acc += A(16 x K) * B(K x 16) where lane (l&15) addresses row `arow` of A and column-row `brow` of B,
-// both K-contiguous in memory; k-steps ks_beg, ks_beg+ks_stride, ...  The loads of U k-steps are issued
-// together before the MFMAs so that one memory round trip covers U steps (these kernels are latency-bound).
+// single-segment form
 template <bool BF16, int U = 8>
 __device__ __forceinline__ f32x4 dot_rows(const float* arow, bool aok, const float* brow, bool bok, int K,
                                           int ks_beg, int ks_stride, bool vec, f32x4 acc) {
-    const int q = (threadIdx.x & 63) >> 4;
-    if (BF16) {
-        const int nks = (K + 31) >> 5;
-        for (int ks0 = ks_beg; ks0 < nks; ks0 += U * ks_stride) {
-            bf16x8 a[U], b[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int ks = ks0 + u * ks_stride;
-                const int k = ks * 32 + 8 * q;
-                const bool in = ks < nks;
-                a[u] = load8_bf16(arow, k, K, aok && in, vec);
-                b[u] = load8_bf16(brow, k, K, bok && in, vec);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc = mma16(a[u], b[u], acc);
-        }
-    } else {
-        const int nks = (K + 3) >> 2;
-        constexpr int UF = 4 * U;
-        for (int ks0 = ks_beg; ks0 < nks; ks0 += UF * ks_stride) {
-            float a[UF], b[UF];
-#pragma unroll
-            for (int u = 0; u < UF; ++u) {
-                const int k = (ks0 + u * ks_stride) * 4 + q;
-                a[u] = (aok && k < K) ? arow[k] : 0.f;
-                b[u] = (bok && k < K) ? brow[k] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < UF; ++u) acc = mma16(a[u], b[u], acc);
-        }
-    }
-    return acc;
+    return dot_rows_cat<BF16, U>(arow, brow, K, vec, arow, brow, 0, vec, aok, bok, ks_beg, ks_stride, acc);
 }

@@ -21,6 +21,25 @@ constexpr int TPW = TT / 4;
 // tanh via one v_exp and one v_rcp: 1 - 2/(1+e^{2x}); absolute error ~2e-7 (the energy kernels evaluate ~6 M of these per step)
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
+// A batch of U strided global reads per thread whose values are consumed LATER (usually stored to LDS): the loads are
+// unconditional from clamped indices, so several batches can be put in flight back to back and cost one round trip in
+// all.  (A plain `for (i = tid; i < n; i += nthr) lds[i] = g[i];` costs one serialized round trip per iteration: the
+// compiler branches around each bounds-checked load and waits for it.)  Elements beyond U*nthr: `rest`.
+template <int U> struct Stage {
+    float v[U];
+    template <typename L> __device__ __forceinline__ void load(int n, int tid, int nthr, L ld) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld(max(min(tid + u * nthr, n - 1), 0));
+    }
+    template <typename S> __device__ __forceinline__ void store(int n, int tid, int nthr, S st) const {
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (tid + u * nthr < n) st(tid + u * nthr, v[u]);
+    }
+    template <typename L, typename S> __device__ __forceinline__ void rest(int n, int tid, int nthr, L ld, S st) const {
+        for (int i = tid + U * nthr; i < n; i += nthr) st(i, ld(i));
+    }
+};
+
 struct DecP {
     asr_dec_dims_t d;
     asr_dec_weights_t w;
@@ -138,19 +157,23 @@ __global__ __launch_bounds__(512) void att_energy_kernel(DecP p, int t) {
     float* s_conv = s_wc + ((d.Kn * taps + 3) & ~3);    // [Kn*TE]          conv output of the tile
     float* s_wp = s_conv + d.Kn * TE;                   // [Kn][A]          W_proj transposed
     float* s_part = s_wp + ((d.Kn * d.A + 3) & ~3);     // [parts][Kn*TE]   partial conv sums
-    // ---- stage 0: every global read that does not depend on the convolution
-    {
-        const float* prev = (t > 0) ? p.s.att + ((long)b * d.L + (t - 1)) * d.Tp : nullptr;
-        const float uni = 1.f / (float)max(len, 1);
-        for (int i = tid; i < win; i += 512) {
-            const int tau = tau0 + i - d.Ks;
-            float v = 0.f;
-            if (tau >= 0 && tau < d.Tp) v = prev ? prev[tau] : (tau < len ? uni : 0.f);
-            s_pa[i] = v;
-        }
-        for (int i = tid; i < d.Kn * taps; i += 512) s_wc[i] = p.w.Wconv[i];
-        for (int i = tid; i < d.Kn * d.A; i += 512) { const int a = i / d.Kn, k = i - a * d.Kn; s_wp[k * d.A + a] = p.w.Wproj[i]; }
-    }
+    // ---- stage 0: every global read that does not depend on the convolution, all in flight together
+    const float* prev = (t > 0) ? p.s.att + ((long)b * d.L + (t - 1)) * d.Tp : nullptr;
+    const float uni = 1.f / (float)max(len, 1);
+    auto ld_pa = [&](int i) { return prev[min(max(tau0 + i - d.Ks, 0), d.Tp - 1)]; };
+    auto st_pa = [&](int i, float v) {
+        const int tau = tau0 + i - d.Ks;
+        s_pa[i] = (tau >= 0 && tau < d.Tp) ? (prev ? v : (tau < len ? uni : 0.f)) : 0.f;
+    };
+    auto ld_wc = [&](int i) { return p.w.Wconv[i]; };
+    auto st_wc = [&](int i, float v) { s_wc[i] = v; };
+    auto ld_wp = [&](int i) { return p.w.Wproj[i]; };
+    auto st_wp = [&](int i, float v) { const int a = i / d.Kn, k = i - a * d.Kn; s_wp[k * d.A + a] = v; };
+    Stage<2> g_pa; Stage<4> g_wc; Stage<6> g_wp;
+    g_pa.v[0] = g_pa.v[1] = 0.f;
+    if (prev) g_pa.load(win, tid, 512, ld_pa);
+    g_wc.load(d.Kn * taps, tid, 512, ld_wc);
+    g_wp.load(d.Kn * d.A, tid, 512, ld_wp);
     const float* qrow = p.s.q + ((long)b * d.L + t) * d.A;
     const int tmax = max(len - 1, 0);
     float kv[NA][TPW], qa[NA], wga[NA];
@@ -164,6 +187,12 @@ __global__ __launch_bounds__(512) void att_energy_kernel(DecP p, int t) {
         }
     };
     load_cols(0);
+    g_pa.store(win, tid, 512, st_pa);
+    g_wc.store(d.Kn * taps, tid, 512, st_wc);
+    g_wp.store(d.Kn * d.A, tid, 512, st_wp);
+    g_pa.rest(win, tid, 512, [&](int i) { return prev ? ld_pa(i) : 0.f; }, st_pa);
+    g_wc.rest(d.Kn * taps, tid, 512, ld_wc, st_wc);
+    g_wp.rest(d.Kn * d.A, tid, 512, ld_wp, st_wp);
     __syncthreads();
     // ---- stage 1: conv[k][i] = sum_j Wconv[k][j] * pa[i + j];  item = (tap range, k, group of 4 frames)
     {
@@ -549,20 +578,22 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
     const float* att = p.f.s.att + row * d.Tp;
     const float* dnext = p.datt_next + (long)b * d.Tp;
 
-    // ---- stage 0: all global reads
-    float dot = 0.f;
-    for (int e = tid; e < d.E; e += nthr) {
-        const float dc = p.dxin[row * XW + d.Dd + e];
-        s_dctx[e] = dc;
-        dot += dc * p.f.s.xin[row * XW + d.Dd + e];
-    }
-    if (!last) for (int i = tid; i < len; i += nthr) dot += att[i] * dnext[i];
-    for (int i = tid; i < d.Kn * TE; i += nthr) {
-        const int k = i / TE, ti = i - k * TE;
-        s_cv[ti * KP + k] = (tau0 + ti < d.Tp) ? convrow[(long)k * d.Tp + tau0 + ti] : 0.f;
-    }
-    for (int i = tid; i < d.Kn * d.A; i += nthr) { const int a = i / d.Kn, k = i - a * d.Kn; s_wpT[k * AP + a] = p.f.w.Wproj[i]; }
-    for (int i = tid; i < d.Kn * (AP - d.A); i += nthr) { const int k = i / (AP - d.A); s_wpT[k * AP + d.A + (i - k * (AP - d.A))] = 0.f; }
+    // ---- stage 0: all global reads, in flight together (consumed after the key/dkey chunk has been requested too)
+    auto ld_dc = [&](int e) { return p.dxin[row * XW + d.Dd + e]; };
+    auto ld_cx = [&](int e) { return p.f.s.xin[row * XW + d.Dd + e]; };
+    auto ld_at = [&](int i) { return att[i]; };
+    auto ld_dn = [&](int i) { return dnext[i]; };
+    auto ld_cv = [&](int i) { const int k = i / TE, ti = i - k * TE; return convrow[(long)k * d.Tp + min(tau0 + ti, d.Tp - 1)]; };
+    auto st_cv = [&](int i, float v) { const int k = i / TE, ti = i - k * TE; s_cv[ti * KP + k] = (tau0 + ti < d.Tp) ? v : 0.f; };
+    auto ld_wp = [&](int i) { return p.f.w.Wproj[i]; };
+    auto st_wp = [&](int i, float v) { const int a_ = i / d.Kn, k = i - a_ * d.Kn; s_wpT[k * AP + a_] = v; };
+    Stage<2> g_dc, g_cx, g_at, g_dn, g_cv; Stage<6> g_wp;
+    g_dc.load(d.E, tid, nthr, ld_dc);
+    g_cx.load(d.E, tid, nthr, ld_cx);
+    g_at.load(max(len, 1), tid, nthr, ld_at);
+    g_dn.load(max(len, 1), tid, nthr, ld_dn);
+    g_cv.load(d.Kn * TE, tid, nthr, ld_cv);
+    g_wp.load(d.Kn * d.A, tid, nthr, ld_wp);
     const int a = 64 * wa + lane;
     const bool aok = a < d.A;
     const int ac = aok ? a : d.A - 1;
@@ -585,6 +616,23 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
         }
     };
     load_chunk(f_beg);
+    float dot = 0.f;
+    {
+        g_dc.store(d.E, tid, nthr, [&](int e, float v) { s_dctx[e] = v; });
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (tid + u * nthr < d.E) dot += g_dc.v[u] * g_cx.v[u];
+        for (int e = tid + 2 * nthr; e < d.E; e += nthr) { const float dc = ld_dc(e); s_dctx[e] = dc; dot += dc * ld_cx(e); }
+        if (!last) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (tid + u * nthr < len) dot += g_at.v[u] * g_dn.v[u];
+            for (int i = tid + 2 * nthr; i < len; i += nthr) dot += att[i] * dnext[i];
+        }
+        g_cv.store(d.Kn * TE, tid, nthr, st_cv);
+        g_cv.rest(d.Kn * TE, tid, nthr, ld_cv, st_cv);
+        g_wp.store(d.Kn * d.A, tid, nthr, st_wp);
+        g_wp.rest(d.Kn * d.A, tid, nthr, ld_wp, st_wp);
+        for (int i = tid; i < d.Kn * (AP - d.A); i += nthr) { const int k = i / (AP - d.A); s_wpT[k * AP + d.A + (i - k * (AP - d.A))] = 0.f; }
+    }
     __syncthreads();
     // ---- stage 1: dattn of the tile (16 lanes per frame, float4 over E), block-wide dot, de
     {
@@ -595,10 +643,18 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
             const float* er = p.f.enc + ((long)b * d.Tp + min(tau, tmax)) * d.E;
             float v = 0.f;
             if (vec) {
-                for (int e = 4 * part; e < d.E; e += 64) {
-                    const float4 x = *reinterpret_cast<const float4*>(er + e);
-                    const float4 c = *reinterpret_cast<const float4*>(s_dctx + e);
-                    v += x.x * c.x + x.y * c.y + x.z * c.z + x.w * c.w;
+                // E/64 float4 per lane, ten at a time in flight (clamped address, contribution zeroed by the LDS operand)
+                for (int e0 = 4 * part; e0 < d.E; e0 += 640) {
+                    float4 x[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) x[u] = *reinterpret_cast<const float4*>(er + min(e0 + 64 * u, d.E - 4));
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) {
+                        if (e0 + 64 * u < d.E) {
+                            const float4 c = *reinterpret_cast<const float4*>(s_dctx + e0 + 64 * u);
+                            v += x[u].x * c.x + x[u].y * c.y + x[u].z * c.z + x[u].w * c.w;
+                        }
+                    }
                 }
             } else {
                 for (int e = part; e < d.E; e += 16) v += er[e] * s_dctx[e];

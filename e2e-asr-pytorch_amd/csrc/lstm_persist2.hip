@@ -21,6 +21,7 @@
 //    in issue order, so a poll that shares a wave with bulk stores is not seen before those have completed.
 // Hand-off, bounded spins and the abort word are as in lstm_persist.hip (guide form R2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -51,7 +52,12 @@ struct P2 {
     unsigned* abort_flag;
     int B, T, H, ND, P;
     int allow_local;     // 1: use XCD-local hand-offs when all workgroups of a direction share an XCD
+    int poll_delay;      // the polling waves sleep this many x 128 clocks at the start of a step, while nothing can have been published yet
 };
+// units of s_sleep(2) = 128 clocks: the first polling round of a step is started roughly when the producers' stores of that
+// step become visible (a round started earlier returns stale data and costs a full round trip, ~0.6 us under this traffic)
+#define POLL_DELAY_FWD 12
+#define POLL_DELAY_BWD 8
 
 __device__ __forceinline__ u64 ld_gran(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_gran(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_p2(P2 p) {
             __bf16* tile = tiles + (s & 1) * 16 * LD;
             if (s > 0 && cnt > 0) {
                 u64 glo[CH], ghi[CH];
+                for (int z = 0; z < p.poll_delay; ++z) __builtin_amdgcn_s_sleep(2);
                 const u64* src = p.xbuf + ((long)((s - 1) & 1) * ND + d) * xregion + 2 * gt;
                 const int sp = gather16<CH>(src, 512, cnt, FWD_MASK, fwd_want(seq_of(s - 1)), glo, ghi, p.abort_flag);
                 DIAG2_MARK(0)
@@ -329,6 +336,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_p2(P2 p) {
             if (s > 0) {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                 if (gb < B && cntp > 0) {
+                    for (int z = 0; z < p.poll_delay; ++z) __builtin_amdgcn_s_sleep(2);
                     const u64* src = p.xbuf + (long)((s - 1) & 1) * per_par + (((long)d * P + me) * P + pp_lo) * B * 8 + gb * 8 + 2 * g4;
                     u64 glo[NTO], ghi[NTO];
                     gather16<NTO>(src, (long)B * 8, cntp, BWD_MASK, bwd_want(seq_of(s - 1)), glo, ghi, p.abort_flag);
@@ -498,6 +506,14 @@ int allow_local() {
     if (on < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); on = (e && e[0] == '0') ? 0 : 1; }
     return on;
 }
+int poll_delay(bool bwd) {
+    static int df = -1, db = -1;
+    if (df < 0) {
+        const char* e = getenv("ASR_LSTM_POLL_DELAY_FWD"); df = e ? atoi(e) : POLL_DELAY_FWD;
+        e = getenv("ASR_LSTM_POLL_DELAY_BWD"); db = e ? atoi(e) : POLL_DELAY_BWD;
+    }
+    return bwd ? db : df;
+}
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -523,7 +539,7 @@ int lstm_fwd_persistent2(float* gates, const float* whh, const float* bias2, flo
     const size_t need = 256 + 2 * (size_t)ND * fwd_region(B, H) * sizeof(u64);
     if (ws_bytes < need) return 1;
     hipMemsetAsync(ws, 0, need, st);
-    P2 p{gates, whh, bias2, y, c, (u64*)((char*)ws + 256), (unsigned*)ws, B, T, H, ND, H / 16, allow_local()};
+    P2 p{gates, whh, bias2, y, c, (u64*)((char*)ws + 256), (unsigned*)ws, B, T, H, ND, H / 16, allow_local(), poll_delay(false)};
     const int nks = (H + 31) / 32;
     FWD2_CASE(1) FWD2_CASE(2) FWD2_CASE(4) FWD2_CASE(6) FWD2_CASE(8) FWD2_CASE(10) FWD2_CASE(12) FWD2_CASE(16)
     return 1;
@@ -537,7 +553,7 @@ int lstm_bwd_persistent2(float* gates, const float* whh, const float* dy, const 
     if (ws_bytes < need) return 1;
     hipMemsetAsync(ws, 0, need, st);
     P2 p{gates, whh, nullptr, const_cast<float*>(dy), const_cast<float*>(c), (u64*)((char*)ws + 256), (unsigned*)ws,
-         B, T, H, ND, (int)P, allow_local()};
+         B, T, H, ND, (int)P, allow_local(), poll_delay(true)};
     const int nto = ((int)P + 3) / 4;
     BWD2_CASE(1) BWD2_CASE(2) BWD2_CASE(3) BWD2_CASE(4) BWD2_CASE(5) BWD2_CASE(6) BWD2_CASE(8)
     return 1;

@@ -194,13 +194,13 @@ def main():
     tot = {k: sum(ms for _, ms in v) for k, v in summ.items()}
     roof = None
     calls = summ.get('asr_lstm_bwd', []) if tot.get('asr_lstm_bwd', 0) >= tot.get('asr_lstm_fwd', 0) else summ.get('asr_lstm_fwd', [])
-    name = 'lstm_bwd_persist' if tot.get('asr_lstm_bwd', 0) >= tot.get('asr_lstm_fwd', 0) else 'lstm_fwd_persist'
+    name = 'lstm_bwd_p2' if tot.get('asr_lstm_bwd', 0) >= tot.get('asr_lstm_fwd', 0) else 'lstm_fwd_p2'
     if calls:
         # algorithmic bytes of ONE launch (all T steps of one layer, both directions), fp32 storage:
         #   forward : gate pre-activations read + activated gates written (2*ND*4H), h and c written (2*ND*H) per (b,t); W_hh once
         #   backward: dy, gates, c, c_prev read (ND*H + ND*4H + 2*ND*H), gate gradients written (ND*4H) per (b,t); W_hh once
-        tidx = 5 if name == 'lstm_bwd_persist' else 6
-        per_bt = (ND * Hd + 2 * ND * 4 * Hd + 2 * ND * Hd) if name == 'lstm_bwd_persist' else (2 * ND * 4 * Hd + 2 * ND * Hd)
+        tidx = 5 if name == 'lstm_bwd_p2' else 6
+        per_bt = (ND * Hd + 2 * ND * 4 * Hd + 2 * ND * Hd) if name == 'lstm_bwd_p2' else (2 * ND * 4 * Hd + 2 * ND * Hd)
         nbytes = sum(4.0 * (B * a[tidx] * per_bt + ND * 4 * Hd * Hd) for a, _ in calls)
         secs = sum(ms for _, ms in calls) * 1e-3
         steps_total = sum(a[tidx] for a, _ in calls)

@@ -105,24 +105,39 @@ class RNNLayerFn(torch.autograd.Function):
             dy = dyn
         nbytes = H.lib().asr_lstm_workspace_bytes(B, Hd, ND)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        pre = torch.cuda.Event()
+        pre.record(torch.cuda.current_stream())
         H.call('asr_lstm_bwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(dy), H.ptr(c), B, T, Hd, ND, prec,
                H.ptr(ws), nbytes, st)
         layer.last_ws_bwd = ws
+        H.flush_side(after=pre)       # the upper layer's parameter gradients run beside this recurrence (40 workgroups)
         # gates now holds the gradient wrt the gate pre-activations
         g2 = gates.view(B * T, G)
         x2 = x.view(B * T, Din)
-        splits = H.wgrad_splits(B * T)
-        H.gemm(g2, x2, layer.g_w_ih_cat, G, Din, B * T, G, Din, Din, 0, 0, accum=1, splits=splits, prec=prec)
-        H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_ih_cat), st)
-        H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_hh_cat), st)
         y2 = y.view(B * T, D)
-        for d in range(ND):
-            H.gemm(g2[:, d * 4 * Hd:], y2[:, d * Hd:], layer.g_w_hh_cat[d], 4 * Hd, Hd, B * T, G, D, Hd, 0, 0,
-                   accum=1, splits=splits, seqT=T, bshift=(-1 if d == 0 else 1), prec=prec)
+        splits = H.wgrad_splits(B * T)
+
+        def weight_grads():
+            s_ = H.stream_ptr()
+            H.gemm(g2, x2, layer.g_w_ih_cat, G, Din, B * T, G, Din, Din, 0, 0, accum=1, splits=splits, prec=prec)
+            H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_ih_cat), s_)
+            H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_hh_cat), s_)
+            for d in range(ND):
+                H.gemm(g2[:, d * 4 * Hd:], y2[:, d * Hd:], layer.g_w_hh_cat[d], 4 * Hd, Hd, B * T, G, D, Hd, 0, 0,
+                       accum=1, splits=splits, seqT=T, bshift=(-1 if d == 0 else 1), prec=prec)
+
+        # the input gradient continues the chain; the parameter gradients of this layer are needed only by the optimizer
+        # and run beside the next layer's recurrence on the side stream (single-process runs; under data parallelism they
+        # stay in order so that the bucket's all-reduce can start right behind them)
+        use_side = H.side_enabled() and layer.dp is None
+        if use_side:
+            H.defer_side(weight_grads, gates, x, y)      # issued behind the NEXT layer's recurrence launch (flush_side below)
         dx = None
         if ctx.need_dx:
             dx = _empty((B, T, Din), x)
             H.gemm(g2, layer.w_ih_cat, dx, B * T, Din, G, G, Din, Din, 1, 0, prec=prec)
+        if not use_side:
+            weight_grads()
         if layer.dp is not None:
             layer.dp.bucket_ready(layer.bucket)
         return None, dx, None, None, None, None

@@ -122,6 +122,82 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- side stream for work that is off the backward pass's dependency chain ------------------------
+# Weight-gradient contractions and bias column sums of a layer are needed only by the optimizer, while the chain
+# continues with a 40-workgroup persistent recurrence that leaves most of the chip idle: they run on a second HIP
+# stream beside it.  The backward pass joins the side stream once, when the autograd engine has finished
+# (engine callback), so every reader of .grad on the current stream sees complete gradients.
+# Measured on MI355X (bench.py, 1 GPU): the contractions do run beside the recurrence, but they slow it by 0.7 ms, run
+# 25-40 % slower themselves and the step gains nothing (34.2 vs 34.0 ms) - so this is OFF unless ASR_SIDE_STREAM=1.
+_side = {'stream': None, 'pending': False, 'enabled': os.environ.get('ASR_SIDE_STREAM', '0') == '1', 'deferred': []}
+
+
+def side_enabled():
+    return _side['enabled']
+
+
+class on_side_stream:
+    """with on_side_stream(event, t1, t2, ...): kernels launched inside run on the side stream once `event` (recorded on the
+    producing stream; None = everything issued so far on the current stream) has completed; the listed tensors are kept
+    alive for the side stream (caching-allocator record_stream)."""
+
+    def __init__(self, event, *tensors):
+        self.event = event
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        if _side['stream'] is None:
+            _side['stream'] = torch.cuda.Stream()
+        side = _side['stream']
+        if self.event is not None:
+            side.wait_event(self.event)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return side
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def defer_side(fn, *tensors):
+    """Queues fn() for the side stream.  Its inputs are complete at this point of the current stream (an event is recorded
+    here); it is issued by the next flush_side() - placed right behind the launch of a long, narrow kernel on the current
+    stream, so that the two really run side by side - or by join_side()."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _side['deferred'].append((fn, ev, tensors))
+    if not _side['pending']:
+        _side['pending'] = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side)
+        except RuntimeError:
+            pass                      # not inside a backward pass: the caller joins explicitly
+
+
+def flush_side(after=None):
+    """Issues the deferred work on the side stream.  `after`: an event of the current stream that the side stream waits for
+    too - recorded just before a long narrow kernel is launched, it makes the deferred work start WITH that kernel
+    instead of as soon as its own inputs are ready (when it would only compete with the wide kernels in between)."""
+    todo, _side['deferred'] = _side['deferred'], []
+    for fn, ev, tensors in todo:
+        with on_side_stream(ev, *tensors) as side:
+            if after is not None:
+                side.wait_event(after)
+            fn()
+
+
+def join_side():
+    """Issues what is still deferred, then the current stream waits for everything on the side stream."""
+    flush_side()
+    if _side['stream'] is not None and _side['pending']:
+        torch.cuda.current_stream().wait_stream(_side['stream'])
+    _side['pending'] = False
+
+
 def ptr(t):
     """Device pointer of a CUDA tensor (None -> NULL)."""
     if t is None:

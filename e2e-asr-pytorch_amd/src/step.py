@@ -24,6 +24,8 @@ def train_step(model, optimizer, ctc_crit, att_crit, feat, feat_len, txt, decode
             w = w * dp.ce_weight(txt_len.sum())        # exact global token-mean under data parallelism
         total = total + att_loss * w
     total.backward()
+    from src import hipabi as H
+    H.join_side()          # parameter-gradient work issued on the side stream (no-op when the engine callback already ran)
     grad_mul = 1.0
     if dp is not None:
         dp.finish()

@@ -292,7 +292,12 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(DecP p, int t) {
     float* s_att = smem_f;  // [Tp]
     const float* en = p.s.energy + (long)b * d.Tp;
     float m = -INFINITY;
-    for (int i = threadIdx.x; i < d.Tp; i += 256) { const float v = en[i]; s_att[i] = v; m = fmaxf(m, v); }
+    {
+        Stage<4> g_en;                     // the whole energy row in one round trip (T' <= 1024; the rest in a plain loop)
+        g_en.load(d.Tp, threadIdx.x, 256, [&](int i) { return en[i]; });
+        g_en.store(d.Tp, threadIdx.x, 256, [&](int i, float v) { s_att[i] = v; m = fmaxf(m, v); });
+        g_en.rest(d.Tp, threadIdx.x, 256, [&](int i) { return en[i]; }, [&](int i, float v) { s_att[i] = v; m = fmaxf(m, v); });
+    }
     m = block_max(m, s4);
     float sum = 0.f;
     for (int i = threadIdx.x; i < d.Tp; i += 256) { const float v = expf(s_att[i] - m); s_att[i] = v; sum += v; }
@@ -312,22 +317,17 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(DecP p, int t) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ecol < d.E) {
             const float* ep = p.enc + (long)b * d.Tp * d.E + ecol;
-            int tau = grp;
-            for (; tau + 48 < len; tau += 64) {
-                const float4 v0 = *reinterpret_cast<const float4*>(ep + (long)tau * d.E);
-                const float4 v1 = *reinterpret_cast<const float4*>(ep + (long)(tau + 16) * d.E);
-                const float4 v2 = *reinterpret_cast<const float4*>(ep + (long)(tau + 32) * d.E);
-                const float4 v3 = *reinterpret_cast<const float4*>(ep + (long)(tau + 48) * d.E);
-                const float a0 = s_att[tau], a1 = s_att[tau + 16], a2 = s_att[tau + 32], a3 = s_att[tau + 48];
-                acc.x += a0 * v0.x + a1 * v1.x + a2 * v2.x + a3 * v3.x;
-                acc.y += a0 * v0.y + a1 * v1.y + a2 * v2.y + a3 * v3.y;
-                acc.z += a0 * v0.z + a1 * v1.z + a2 * v2.z + a3 * v3.z;
-                acc.w += a0 * v0.w + a1 * v1.w + a2 * v2.w + a3 * v3.w;
-            }
-            for (; tau < len; tau += 16) {
-                const float4 v0 = *reinterpret_cast<const float4*>(ep + (long)tau * d.E);
-                const float a0 = s_att[tau];
-                acc.x += a0 * v0.x; acc.y += a0 * v0.y; acc.z += a0 * v0.z; acc.w += a0 * v0.w;
+            // 16 frame groups x 16 float4 columns; each thread walks frames grp, grp+16, ... ten at a time in flight
+            // (clamped addresses, weights of frames >= len are read as 0 from the padded attention row)
+            for (int tau = grp; tau < len; tau += 160) {
+                float4 v[10];
+#pragma unroll
+                for (int u = 0; u < 10; ++u) v[u] = *reinterpret_cast<const float4*>(ep + (long)min(tau + 16 * u, len - 1) * d.E);
+#pragma unroll
+                for (int u = 0; u < 10; ++u) {
+                    const float a = (tau + 16 * u < len) ? s_att[tau + 16 * u] : 0.f;
+                    acc.x += a * v[u].x; acc.y += a * v[u].y; acc.z += a * v[u].z; acc.w += a * v[u].w;
+                }
             }
         }
         __shared__ float4 red4[16][16];
@@ -864,7 +864,10 @@ __global__ __launch_bounds__(512) void wconv_grad_kernel(DecP p, float* __restri
 
 // B4: query backward.  dq[b,t,:] already holds the gradient wrt the query pre-activation;  dhs[b,t-1,:] += dq * W_q.
 template <bool BF16>
-__global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t) {
+__global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t, int fuse_elem) {
+    // fuse_elem (single-layer decoders): dhs[b,t-1,:] is complete once this kernel has added its part, so the same
+    // thread goes on with the cell backward of step t-1 for its (row, unit) - the elementwise kernel of that step and
+    // its launch boundary are saved.  Operands of that epilogue are requested before the contraction.
     __shared__ float red[4][256];
     const asr_dec_dims_t& d = p.f.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
@@ -875,15 +878,40 @@ __global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t) {
         const int ab = m0 + n;
         const bool rok = ab < d.B;
         const float* drow = p.dq + ((long)(rok ? ab : 0) * d.L + t) * d.A;
+        const int row = tid >> 4, col = tid & 15;
+        const int b = m0 + row, cc = blockIdx.x * 16 + col;
+        const bool ook = b < d.B && cc < d.Q;
+        const long ri = (long)(ook ? b : 0) * d.L + (t - 1);
+        float* dh = p.dhs + ri * d.Q + (ook ? cc : 0);
+        const float dh_old = *dh;
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cp = 0.f, carry = 0.f;
+        float* g = p.f.s.gates + ri * 4 * d.Dd + (ook ? cc : 0);          // NL == 1 when fuse_elem
+        const long ci = (long)(ook ? b : 0) * d.Dd + (ook ? cc : 0);
+        if (fuse_elem) {
+            gi = g[0]; gf = g[d.Dd]; gg = g[2 * d.Dd]; go = g[3 * d.Dd];
+            ct = p.f.s.cs[ri * d.Dd + (ook ? cc : 0)];
+            cp = p.f.s.cs[(ri - (t > 1 ? 1 : 0)) * d.Dd + (ook ? cc : 0)];
+            if (t <= 1) cp = 0.f;
+            carry = p.dcf[ci];
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = dot_rows<BF16>(drow, rok, wrow, cok, d.A, wave, 4, (d.A % 4) == 0, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 16 + n] = acc[r];
         __syncthreads();
-        const int row = tid >> 4, col = tid & 15;
-        const int b = m0 + row, cc = blockIdx.x * 16 + col;
-        if (b < d.B && cc < d.Q)
-            p.dhs[((long)b * d.L + (t - 1)) * d.Q + cc] += red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (ook) {
+            const float dhv = dh_old + red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            *dh = dhv;
+            if (fuse_elem) {
+                const float tc = tanhf(ct);
+                const float dc = dhv * go * (1.f - tc * tc) + carry;
+                g[0] = dc * gg * gi * (1.f - gi);
+                g[d.Dd] = dc * cp * gf * (1.f - gf);
+                g[2 * d.Dd] = dc * gi * (1.f - gg * gg);
+                g[3 * d.Dd] = dhv * tc * go * (1.f - go);
+                p.dcf[ci] = dc * gf;
+            }
+        }
         __syncthreads();
     }
 }
@@ -1214,8 +1242,10 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     const dim3 grid_c(cdiv(d.Tp, lay.TC), d.B);
     for (int t = d.L - 1; t >= 0; --t) {
         const int last = (t == d.L - 1);
+        const int fuse = (d.NL == 1) ? 1 : 0;    // the cell backward's elementwise part rides on the previous query backward
         for (int l = d.NL - 1; l >= 0; --l) {
-            hipLaunchKernelGGL(dec_cell_bwd_elem_kernel, dim3(cdiv(d.B * d.Dd, 256)), dim3(256), 0, st, p, t, l, last);
+            if (!fuse || last)
+                hipLaunchKernelGGL(dec_cell_bwd_elem_kernel, dim3(cdiv(d.B * d.Dd, 256)), dim3(256), 0, st, p, t, l, last);
             const int width = ((l == 0) ? XW : d.Dd) + d.Dd;
             if (bf) hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<true>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
             else    hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<false>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
@@ -1226,8 +1256,8 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         if (t > 0) {
             // the location path reaches attn_{t-1}; step 0 convolves the constant initial attention
             hipLaunchKernelGGL(att_bwd_conv_kernel, grid_c, dim3(512), lay.lds_c, st, p, t, lay.TC);
-            if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);
-            else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t);
+            if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t, fuse);
+            else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t, fuse);
         }
     }
     ASR_LAUNCH_CHECK("asr_att_decoder_bwd");
@@ -1244,9 +1274,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         rc = asr_gemm(dg, state->hs + (size_t)l * d.Dd, grads->Whh[l], nullptr, 4 * d.Dd, d.Dd, BL, ldg, SW, d.Dd, 0, 0, ASR_ACT_NONE,
                       1, 1, 1, 0, 0, 0, d.L, -1, prec, stream);
         if (rc != ASR_OK) return rc;
-        rc = asr_colsum(dg, ldg, BL, 4 * d.Dd, grads->bih[l], stream);
-        if (rc != ASR_OK) return rc;
-        rc = asr_colsum(dg, ldg, BL, 4 * d.Dd, grads->bhh[l], stream);
+        rc = asr_colsum2(dg, ldg, BL, 4 * d.Dd, grads->bih[l], grads->bhh[l], stream);
         if (rc != ASR_OK) return rc;
     }
     // query projection: dW_q += dqpre^T hcat_{t-1}, db_q += colsum(dqpre)

@@ -53,7 +53,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dout, const float* __re
 
 // column sums of a (M,N) matrix with row stride lda, atomically added into out[N]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, long lda, int M, int N,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ out, float* __restrict__ out2, int rows_per_block) {
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int grp = threadIdx.x >> 6;
@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
         for (int r = r0 + grp; r < r1; r += 4) s += A[(long)r * lda + col];
     red[grp][threadIdx.x & 63] = s;
     __syncthreads();
-    if (grp == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (grp == 0 && col < N) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(out + col, v);
+        if (out2) atomicAdd(out2 + col, v);
+    }
 }
 
 // one wave per row: out = x - logsumexp(x)
@@ -193,13 +197,16 @@ extern "C" int asr_act_bwd(const float* dout, const float* out, float* dpre, lon
     return ASR_OK;
 }
 
-extern "C" int asr_colsum(const float* A, long lda, int M, int N, float* out, asr_stream_t stream) {
+extern "C" int asr_colsum2(const float* A, long lda, int M, int N, float* out, float* out2, asr_stream_t stream) {
     ASR_REQUIRE(A && out && M > 0 && N > 0 && lda >= N, ASR_E_ARG, "asr_colsum: bad args");
     const int rows_per_block = 512;
     dim3 grid(cdiv(N, 64), cdiv(M, rows_per_block));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, M, N, out, rows_per_block);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, M, N, out, out2, rows_per_block);
     ASR_LAUNCH_CHECK("asr_colsum");
     return ASR_OK;
+}
+extern "C" int asr_colsum(const float* A, long lda, int M, int N, float* out, asr_stream_t stream) {
+    return asr_colsum2(A, lda, M, N, out, nullptr, stream);
 }
 
 extern "C" int asr_log_softmax(const float* x, float* out, long rows, int V, asr_stream_t stream) {

@@ -120,8 +120,7 @@ class RNNLayerFn(torch.autograd.Function):
         def weight_grads():
             s_ = H.stream_ptr()
             H.gemm(g2, x2, layer.g_w_ih_cat, G, Din, B * T, G, Din, Din, 0, 0, accum=1, splits=splits, prec=prec)
-            H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_ih_cat), s_)
-            H.call('asr_colsum', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_hh_cat), s_)
+            H.call('asr_colsum2', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_ih_cat), H.ptr(layer.g_b_hh_cat), s_)
             for d in range(ND):
                 H.gemm(g2[:, d * 4 * Hd:], y2[:, d * Hd:], layer.g_w_hh_cat[d], 4 * Hd, Hd, B * T, G, D, Hd, 0, 0,
                        accum=1, splits=splits, seqT=T, bshift=(-1 if d == 0 else 1), prec=prec)

@@ -46,6 +46,7 @@ SIGNATURES = {
     'asr_dropout_mask': [_vp, _l, _f, _u64, _vp],
     'asr_act_bwd': [_vp, _vp, _vp, _l, _i, _vp],
     'asr_colsum': [_vp, _l, _i, _i, _vp, _vp],
+    'asr_colsum2': [_vp, _l, _i, _i, _vp, _vp, _vp],
     'asr_log_softmax': [_vp, _vp, _l, _i, _vp],
     'asr_logsoftmax_relu_bwd': [_vp, _vp, _vp, _vp, _l, _i, _vp],
     'asr_layernorm_fwd': [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp],

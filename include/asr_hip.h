@@ -106,6 +106,8 @@ int asr_dropout_mask(float* mask, long n, float p, uint64_t seed, asr_stream_t s
 int asr_act_bwd(const float* dout, const float* out, float* dpre, long n, int act, asr_stream_t stream);
 /* out[j] += sum_i A[i*lda + j]  (bias gradients). */
 int asr_colsum(const float* A, long lda, int M, int N, float* out, asr_stream_t stream);
+/* the same sums added to two vectors (an LSTM's bias_ih and bias_hh gradients are the same column sums); out2 may be NULL */
+int asr_colsum2(const float* A, long lda, int M, int N, float* out, float* out2, asr_stream_t stream);
 /* row-wise log_softmax (src/asr.py:120) and the backward of log_softmax(ReLU(.)) of the CTC head
  * (src/asr.py:29-32,120): dpre = (act > 0) ? dlogp - exp(logp) * rowsum(dlogp) : 0. */
 int asr_log_softmax(const float* x, float* out, long rows, int V, asr_stream_t stream);

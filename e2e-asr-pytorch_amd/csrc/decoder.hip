@@ -40,6 +40,16 @@ template <int U> struct Stage {
     }
 };
 
+__device__ __forceinline__ float bf2f(unsigned short x) { return __uint_as_float((unsigned)x << 16); }
+// four consecutive bf16 (8 bytes, 8-byte aligned) -> float4
+__device__ __forceinline__ float4 ld4_bf16(const unsigned short* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = f2bf_bits(src[i]);
+}
+
 struct DecP {
     asr_dec_dims_t d;
     asr_dec_weights_t w;
@@ -143,7 +153,7 @@ __device__ __forceinline__ void conv_tile(const DecP& p, int b, int t, int tau0,
 // convolution is computed; the convolution itself is spread over all 512 threads (tap ranges x 4-frame groups).
 // conv (B,L,Kn,T') is kept for the backward pass when state.conv != NULL.
 // ------------------------------------------------------------------------------------------------
-template <int KNMAX, int TPW>
+template <int KNMAX, int TPW, bool H16>
 __global__ __launch_bounds__(512) void att_energy_kernel(DecP p, int t) {
     constexpr int TE = 8 * TPW, NA = 5;                 // NA: attention columns per lane held in flight
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -183,7 +193,10 @@ __global__ __launch_bounds__(512) void att_energy_kernel(DecP p, int t) {
             const int a = min(a0 + 64 * c + lane, d.A - 1);
             qa[c] = qrow[a]; wga[c] = p.w.wg[a];
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) kv[c][i] = p.s.key[((long)b * d.Tp + min(tau0 + wave * TPW + i, tmax)) * d.A + a];
+            for (int i = 0; i < TPW; ++i) {
+                const long ki = ((long)b * d.Tp + min(tau0 + wave * TPW + i, tmax)) * d.A + a;
+                kv[c][i] = H16 ? bf2f(reinterpret_cast<const unsigned short*>(p.s.key16)[ki]) : p.s.key[ki];
+            }
         }
     };
     load_cols(0);
@@ -282,6 +295,7 @@ __device__ __forceinline__ float block_sum(float v, float* s4) {
 // K3: softmax over T' + context.  grid (ceil(E/64), B); every block redoes the (cheap) softmax of its
 // utterance and owns 64 columns of the context vector; block x == 0 also stores the attention row.
 // ------------------------------------------------------------------------------------------------
+template <bool H16>
 __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(DecP p, int t) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     __shared__ float s4[4];
@@ -317,12 +331,16 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(DecP p, int t) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ecol < d.E) {
             const float* ep = p.enc + (long)b * d.Tp * d.E + ecol;
+            const unsigned short* ep16 = reinterpret_cast<const unsigned short*>(p.s.enc16) + (long)b * d.Tp * d.E + ecol;
             // 16 frame groups x 16 float4 columns; each thread walks frames grp, grp+16, ... ten at a time in flight
             // (clamped addresses, weights of frames >= len are read as 0 from the padded attention row)
             for (int tau = grp; tau < len; tau += 160) {
                 float4 v[10];
 #pragma unroll
-                for (int u = 0; u < 10; ++u) v[u] = *reinterpret_cast<const float4*>(ep + (long)min(tau + 16 * u, len - 1) * d.E);
+                for (int u = 0; u < 10; ++u) {
+                    const long off = (long)min(tau + 16 * u, len - 1) * d.E;
+                    v[u] = H16 ? ld4_bf16(ep16 + off) : *reinterpret_cast<const float4*>(ep + off);
+                }
 #pragma unroll
                 for (int u = 0; u < 10; ++u) {
                     const float a = (tau + 16 * u < len) ? s_att[tau + 16 * u] : 0.f;
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_mm_kernel(DecB p, int t, int
 // Threads: NG frame groups x ceil(A/64) waves; wave (g, wa) owns attention dims a = 64*wa + lane for the frames of
 // group g, so the per-a sums have one writer per group and meet in LDS.  TE is chosen by the host so that the batch is
 // one round of workgroups; all global operands are requested before the first barrier.
-template <int KNMAX>
+template <int KNMAX, bool H16>
 __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int TE, int NG, int last) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     __shared__ float s_red[16];
@@ -611,7 +629,7 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
 #pragma unroll
         for (int i = 0; i < CHK; ++i) {
             const long ki = ((long)b * d.Tp + min(tau0 + f0 + i, tmax)) * d.A + ac;
-            kv[i] = p.f.s.key[ki];
+            kv[i] = H16 ? bf2f(reinterpret_cast<const unsigned short*>(p.f.s.key16)[ki]) : p.f.s.key[ki];
             dk[i] = p.dkey[ki];
         }
     };
@@ -641,13 +659,14 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
         for (int f = tid >> 4; f < TE; f += nthr >> 4) {
             const int tau = tau0 + f;
             const float* er = p.f.enc + ((long)b * d.Tp + min(tau, tmax)) * d.E;
+            const unsigned short* er16 = reinterpret_cast<const unsigned short*>(p.f.s.enc16) + ((long)b * d.Tp + min(tau, tmax)) * d.E;
             float v = 0.f;
             if (vec) {
                 // E/64 float4 per lane, ten at a time in flight (clamped address, contribution zeroed by the LDS operand)
                 for (int e0 = 4 * part; e0 < d.E; e0 += 640) {
                     float4 x[10];
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) x[u] = *reinterpret_cast<const float4*>(er + min(e0 + 64 * u, d.E - 4));
+                    for (int u = 0; u < 10; ++u) x[u] = H16 ? ld4_bf16(er16 + min(e0 + 64 * u, d.E - 4)) : *reinterpret_cast<const float4*>(er + min(e0 + 64 * u, d.E - 4));
 #pragma unroll
                     for (int u = 0; u < 10; ++u) {
                         if (e0 + 64 * u < d.E) {
@@ -1050,19 +1069,20 @@ EnergyPlan energy_plan(const asr_dec_dims_t& d) {
                               (size_t)parts * d.Kn * TE);
     return pl;
 }
-template <int KNMAX>
+template <int KNMAX, bool H16>
 void launch_energy_k(const DecP& p, int t, const EnergyPlan& pl, hipStream_t st) {
     switch (pl.tpw) {
-        case 2: hipLaunchKernelGGL((att_energy_kernel<KNMAX, 2>), pl.grid, dim3(512), pl.lds, st, p, t); break;
-        case 4: hipLaunchKernelGGL((att_energy_kernel<KNMAX, 4>), pl.grid, dim3(512), pl.lds, st, p, t); break;
-        case 5: if constexpr (KNMAX <= 10) { hipLaunchKernelGGL((att_energy_kernel<KNMAX, 5>), pl.grid, dim3(512), pl.lds, st, p, t); } break;
-        default: if constexpr (KNMAX <= 4) { hipLaunchKernelGGL((att_energy_kernel<KNMAX, 8>), pl.grid, dim3(512), pl.lds, st, p, t); } break;
+        case 2: hipLaunchKernelGGL((att_energy_kernel<KNMAX, 2, H16>), pl.grid, dim3(512), pl.lds, st, p, t); break;
+        case 4: hipLaunchKernelGGL((att_energy_kernel<KNMAX, 4, H16>), pl.grid, dim3(512), pl.lds, st, p, t); break;
+        case 5: if constexpr (KNMAX <= 10) { hipLaunchKernelGGL((att_energy_kernel<KNMAX, 5, H16>), pl.grid, dim3(512), pl.lds, st, p, t); } break;
+        default: if constexpr (KNMAX <= 4) { hipLaunchKernelGGL((att_energy_kernel<KNMAX, 8, H16>), pl.grid, dim3(512), pl.lds, st, p, t); } break;
     }
 }
 void launch_energy(const DecP& p, int t, const EnergyPlan& pl, hipStream_t st) {
-    if (p.d.Kn <= 4) launch_energy_k<4>(p, t, pl, st);
-    else if (p.d.Kn <= 10) launch_energy_k<10>(p, t, pl, st);
-    else launch_energy_k<16>(p, t, pl, st);
+    const bool h16 = p.s.key16 != nullptr;
+    if (p.d.Kn <= 4) { if (h16) launch_energy_k<4, true>(p, t, pl, st); else launch_energy_k<4, false>(p, t, pl, st); }
+    else if (p.d.Kn <= 10) { if (h16) launch_energy_k<10, true>(p, t, pl, st); else launch_energy_k<10, false>(p, t, pl, st); }
+    else { if (h16) launch_energy_k<16, true>(p, t, pl, st); else launch_energy_k<16, false>(p, t, pl, st); }
 }
 
 }  // namespace
@@ -1083,6 +1103,10 @@ extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_wei
     rc = asr_gemm(enc, weights->Wk, state->key, weights->bk, d.B * d.Tp, d.A, d.E, d.E, d.E, d.A, 1, 1, ASR_ACT_TANH, 0, 1,
                   1, 0, 0, 0, 0, 0, prec, stream);
     if (rc != ASR_OK) return rc;
+    // bf16 working copies of the two tensors every step re-reads (bf16 contraction mode only; the caller provides the
+    // buffers): they halve the loop's HBM traffic and bring its per-XCD working set under the 4 MB L2
+    if (state->key16) hipLaunchKernelGGL(cast_bf16_kernel, dim3(1024), dim3(256), 0, st, state->key, (unsigned short*)state->key16, (long)d.B * d.Tp * d.A);
+    if (state->enc16) hipLaunchKernelGGL(cast_bf16_kernel, dim3(1024), dim3(256), 0, st, enc, (unsigned short*)state->enc16, (long)d.B * d.Tp * d.E);
 
     if (teacher) {
         hipLaunchKernelGGL(shift_tokens_kernel, dim3(cdiv(d.B * d.L, 256)), dim3(256), 0, st, teacher, state->tokens, d.B, d.L, teacher_ld);
@@ -1101,7 +1125,8 @@ extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_wei
         if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
         else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
         launch_energy(p, t, epl, st);
-        hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
+        if (state->enc16 && (d.E & 3) == 0) hipLaunchKernelGGL(att_softmax_ctx_kernel<true>, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
+        else hipLaunchKernelGGL(att_softmax_ctx_kernel<false>, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
         for (int l = 0; l < d.NL; ++l) {
             if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
             else    hipLaunchKernelGGL(dec_cell_fwd_kernel<false>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
@@ -1149,7 +1174,8 @@ extern "C" int asr_att_decoder_step(const asr_dec_dims_t* dims, const asr_dec_we
     if (bf) hipLaunchKernelGGL(dec_query_kernel<true>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
     else    hipLaunchKernelGGL(dec_query_kernel<false>, dim3(cdiv(d.A, 16)), dim3(256), 0, st, p, t);
     launch_energy(p, t, epl, st);
-    hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
+    if (state->enc16 && (d.E & 3) == 0) hipLaunchKernelGGL(att_softmax_ctx_kernel<true>, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
+    else hipLaunchKernelGGL(att_softmax_ctx_kernel<false>, dim3(cdiv(d.E, 64), d.B), dim3(256), sizeof(float) * d.Tp, st, p, t);
     for (int l = 0; l < d.NL; ++l) {
         if (bf) hipLaunchKernelGGL(dec_cell_fwd_kernel<true>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
         else    hipLaunchKernelGGL(dec_cell_fwd_kernel<false>, dim3(cdiv(d.Dd, 4)), dim3(256), 0, st, p, t, l);
@@ -1231,14 +1257,18 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
                 "asr_att_decoder_bwd: shape needs %zu / %zu / %zu B of LDS", lay.lds_e, lay.lds_c, lay.lds_w);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void*)att_bwd_energy_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         hipFuncSetAttribute((const void*)att_bwd_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         hipFuncSetAttribute((const void*)wconv_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_set = true;
     }
     const dim3 grid_e(lay.nte, d.B), block_e(64 * nw_e * lay.NG);
+    const bool h16 = state->key16 != nullptr && state->enc16 != nullptr && (d.E & 3) == 0;
     const dim3 grid_c(cdiv(d.Tp, lay.TC), d.B);
     for (int t = d.L - 1; t >= 0; --t) {
         const int last = (t == d.L - 1);
@@ -1250,9 +1280,15 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
             if (bf) hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<true>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
             else    hipLaunchKernelGGL(dec_cell_bwd_mm_kernel<false>, dim3(cdiv(width, 16)), dim3(256), 0, st, p, t, l);
         }
-        if (d.Kn <= 4)       hipLaunchKernelGGL(att_bwd_energy_kernel<4>, grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
-        else if (d.Kn <= 10) hipLaunchKernelGGL(att_bwd_energy_kernel<10>, grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
-        else                 hipLaunchKernelGGL(att_bwd_energy_kernel<16>, grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+        if (h16) {
+            if (d.Kn <= 4)       hipLaunchKernelGGL((att_bwd_energy_kernel<4, true>), grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+            else if (d.Kn <= 10) hipLaunchKernelGGL((att_bwd_energy_kernel<10, true>), grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+            else                 hipLaunchKernelGGL((att_bwd_energy_kernel<16, true>), grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+        } else {
+            if (d.Kn <= 4)       hipLaunchKernelGGL((att_bwd_energy_kernel<4, false>), grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+            else if (d.Kn <= 10) hipLaunchKernelGGL((att_bwd_energy_kernel<10, false>), grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+            else                 hipLaunchKernelGGL((att_bwd_energy_kernel<16, false>), grid_e, block_e, lay.lds_e, st, p, t, lay.TE, lay.NG, last);
+        }
         if (t > 0) {
             // the location path reaches attn_{t-1}; step 0 convolves the constant initial attention
             hipLaunchKernelGGL(att_bwd_conv_kernel, grid_c, dim3(512), lay.lds_c, st, p, t, lay.TC);

@@ -270,11 +270,15 @@ def _dec_tensors(model, grads):
     }
 
 
-def _dec_state(d, dev, save_conv=True):
-    """save_conv: keep the location-convolution output of every step (B,L,Kn,Tp) for the backward pass."""
+def _dec_state(d, dev, save_conv=True, half_copies=False):
+    """save_conv: keep the location-convolution output of every step (B,L,Kn,Tp) for the backward pass.
+    half_copies: bf16 working copies of key and enc for the step kernels (bf16 contraction mode, E % 4 == 0)."""
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    h = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)
     return {
         'conv': f(d.B, d.L, d.Kn, d.Tp) if save_conv else None,
+        'key16': h(d.B, d.Tp, d.A) if half_copies else None,
+        'enc16': h(d.B, d.Tp, d.E) if half_copies else None,
         'key': f(d.B, d.Tp, d.A), 'att': f(d.B, d.L, d.Tp), 'q': f(d.B, d.L, d.A), 'xin': f(d.B, d.L, d.Dd + d.E),
         'gates': f(d.B, d.L, d.NL, 4 * d.Dd), 'cs': f(d.B, d.L, d.NL, d.Dd), 'hs': f(d.B, d.L, d.NL, d.Dd),
         'logits': f(d.B, d.L, d.V), 'energy': f(d.B, d.Tp),
@@ -286,7 +290,7 @@ def att_decoder_forward(model, enc, enc_len, L, teacher, prec):
     """Runs the decode loop; returns (dims, state dict)."""
     B, Tp, _ = enc.shape
     d = _dec_dims(model, B, Tp, L)
-    st = _dec_state(d, enc.device)
+    st = _dec_state(d, enc.device, half_copies=(prec == H.BF16 and d.E % 4 == 0))
     w = H.dec_weights_struct(_dec_tensors(model, False), d.NL)
     s = H.dec_state_struct(st)
     t_ptr, t_ld = (None, 0)

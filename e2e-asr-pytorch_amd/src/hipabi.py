@@ -31,7 +31,7 @@ class DecWeights(ctypes.Structure):
 
 
 class DecState(ctypes.Structure):
-    _fields_ = [(n, _vp) for n in ('key', 'att', 'q', 'xin', 'gates', 'cs', 'hs', 'logits', 'energy', 'conv', 'tokens')]
+    _fields_ = [(n, _vp) for n in ('key', 'att', 'q', 'xin', 'gates', 'cs', 'hs', 'logits', 'energy', 'conv', 'key16', 'enc16', 'tokens')]
 
 
 _P = ctypes.POINTER

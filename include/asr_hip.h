@@ -186,6 +186,8 @@ typedef struct {        /* forward outputs / saved activations, caller-allocated
     float* logits;      /* (B,L,V)    att_output */
     float* energy;      /* (B,Tp)     scratch */
     float* conv;        /* (B,L,Kn,Tp) location-convolution output per step, kept for backward; may be NULL for inference */
+    void* key16;        /* (B,Tp,A) bf16 working copy of key for the step kernels; NULL = read the fp32 tensor (fp32 mode) */
+    void* enc16;        /* (B,Tp,E) bf16 working copy of enc, filled by asr_att_decoder_fwd; NULL = read enc */
     int64_t* tokens;    /* (B,L)      input token of each step (<sos>=0 first) */
 } asr_dec_state_t;
 

@@ -31,7 +31,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=1200)
     ap.add_argument('--tokens', type=int, default=180)

@@ -115,15 +115,16 @@ class RNNLayerFn(torch.autograd.Function):
         g2 = gates.view(B * T, G)
         x2 = x.view(B * T, Din)
         y2 = y.view(B * T, D)
-        splits = H.wgrad_splits(B * T)
+        splits_ih = H.wgrad_splits(B * T, G, Din)
+        splits_hh = H.wgrad_splits(B * T, 4 * Hd, Hd)
 
         def weight_grads():
             s_ = H.stream_ptr()
-            H.gemm(g2, x2, layer.g_w_ih_cat, G, Din, B * T, G, Din, Din, 0, 0, accum=1, splits=splits, prec=prec)
+            H.gemm(g2, x2, layer.g_w_ih_cat, G, Din, B * T, G, Din, Din, 0, 0, accum=1, splits=splits_ih, prec=prec)
             H.call('asr_colsum2', H.ptr(g2), G, B * T, G, H.ptr(layer.g_b_ih_cat), H.ptr(layer.g_b_hh_cat), s_)
             for d in range(ND):
                 H.gemm(g2[:, d * 4 * Hd:], y2[:, d * Hd:], layer.g_w_hh_cat[d], 4 * Hd, Hd, B * T, G, D, Hd, 0, 0,
-                       accum=1, splits=splits, seqT=T, bshift=(-1 if d == 0 else 1), prec=prec)
+                       accum=1, splits=splits_hh, seqT=T, bshift=(-1 if d == 0 else 1), prec=prec)
 
         # the input gradient continues the chain; the parameter gradients of this layer are needed only by the optimizer
         # and run beside the next layer's recurrence on the side stream (single-process runs; under data parallelism they

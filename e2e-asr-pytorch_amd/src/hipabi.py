@@ -229,9 +229,15 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_kc=1, b_kc=1, bias=None, act=ACT_NON
          a_kc, b_kc, act, accum, splits, batch, sA, sB, sC, seqT, bshift, prec, stream_ptr())
 
 
-def wgrad_splits(rows):
-    """Number of reduction slices for a weight-gradient contraction over `rows` = B*T rows."""
-    return max(1, min(32, rows // 1024))
+def wgrad_splits(rows, out_rows=None, out_cols=None):
+    """Number of reduction slices for a weight-gradient contraction over `rows` = B*T rows into an (out_rows, out_cols)
+    matrix: enough 128x128 output tiles x slices to fill the chip ONCE at its residency of ~3.5 workgroups per CU (a
+    second, partial round of workgroups costs as much as a full one: measured 247 us at 9 slices vs 296 us at 18 for
+    the 2560x640 gradient), each slice at least 512 rows deep."""
+    if out_rows is None:
+        return max(1, min(32, rows // 1024))
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    return max(1, min(64, rows // 512, int(round(900.0 / tiles))))
 
 
 def linear_fwd(x2d, W, b, out2d, act=ACT_NONE, prec=BF16):
@@ -245,7 +251,7 @@ def linear_bwd(x2d, W, dy2d, dW, db, dx2d=None, prec=BF16, accum_dx=0):
     """dW += dy^T x ; db += colsum(dy) ; dx (=|+=) dy W."""
     M, K = x2d.shape
     N = W.shape[0]
-    gemm(dy2d, x2d, dW, N, K, M, dy2d.stride(0), x2d.stride(0), dW.stride(0), 0, 0, accum=1, splits=wgrad_splits(M), prec=prec)
+    gemm(dy2d, x2d, dW, N, K, M, dy2d.stride(0), x2d.stride(0), dW.stride(0), 0, 0, accum=1, splits=wgrad_splits(M, N, K), prec=prec)
     if db is not None:
         call('asr_colsum', ptr(dy2d), dy2d.stride(0), M, N, ptr(db), stream_ptr())
     if dx2d is not None:

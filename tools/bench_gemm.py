@@ -34,3 +34,8 @@ run('wgrad in-proj L1 (dy^T x)', 2560, 640, 19200, 0, 0, splits=18, accum=1)
 run('wgrad in-proj L2', 2560, 640, 9600, 0, 0, splits=9, accum=1)
 run('wgrad W_hh L1', 1280, 320, 19200, 0, 0, splits=18, accum=1)
 run('wgrad proj', 640, 640, 19200, 0, 0, splits=18, accum=1)
+print('--- split sweep, wgrad in-proj L1')
+for sp in (2, 4, 6, 9, 12, 18, 24, 32):
+    run('wgrad in-proj L1', 2560, 640, 19200, 0, 0, splits=sp, accum=1)
+for sp in (4, 9, 18, 32):
+    run('wgrad W_hh L1', 1280, 320, 19200, 0, 0, splits=sp, accum=1)

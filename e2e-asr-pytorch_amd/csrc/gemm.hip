@@ -215,8 +215,10 @@ __device__ __forceinline__ float frag_f32(const void* lds, int row0, int ks) {
     else    return s[k * TileLayout<false, false>::LD + row];
 }
 
-template <bool BF16, bool AKC, bool BKC>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+// FAST: both operands qualify for fetch_tile_fast; the generic loader (ragged extents, convolution operand) is then not
+// compiled in at all - it alone costs ~80 VGPRs and halves the occupancy (2 -> 4 workgroups per CU).
+template <bool BF16, bool AKC, bool BKC, bool FAST>
+__global__ __launch_bounds__(NT, (FAST && BF16) ? 3 : 1) void gemm_kernel(GemmP p) {
     constexpr int A_BYTES = TileLayout<BF16, AKC>::ELEMS * (BF16 ? 2 : 4);
     constexpr int B_BYTES = TileLayout<BF16, BKC>::ELEMS * (BF16 ? 2 : 4);
     __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
@@ -273,9 +275,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 
     float4 ra[4], rb[4];
     auto fetch = [&](int kk) {
-        if (p.fastA) fetch_tile_fast<AKC>(A, p.lda, i0, p.M, kk, p.K, 0, 0, ra);
+        if (FAST || p.fastA) fetch_tile_fast<AKC>(A, p.lda, i0, p.M, kk, p.K, 0, 0, ra);
         else fetch_tile<AKC>(A, p.lda, i0, p.M, kk, p.K, p.vecA, 0, 0, ra, p.convA, p.cT, p.cF, p.cC);
-        if (p.fastB) fetch_tile_fast<BKC>(B, p.ldb, j0, p.N, kk, p.K, BKC ? 0 : p.seqT, p.bshift, rb);
+        if (FAST || p.fastB) fetch_tile_fast<BKC>(B, p.ldb, j0, p.N, kk, p.K, BKC ? 0 : p.seqT, p.bshift, rb);
         else fetch_tile<BKC>(B, p.ldb, j0, p.N, kk, p.K, p.vecB, BKC ? 0 : p.seqT, p.bshift, rb, p.convB, p.cT, p.cF, p.cC);
     };
     fetch(kt0 * BK);
@@ -361,10 +363,17 @@ int launch_gemm(const GemmP& p0, int a_kc, int b_kc, hipStream_t st) {
     ASR_REQUIRE(nblk < (1L << 31), ASR_E_UNSUPPORTED, "asr_gemm: %ld tiles", nblk);
     dim3 grid((unsigned)nblk);
     dim3 block(NT);
-    if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_kernel<BF16, true, true>), grid, block, 0, st, p);
-    else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_kernel<BF16, true, false>), grid, block, 0, st, p);
-    else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<BF16, false, false>), grid, block, 0, st, p);
-    else                     hipLaunchKernelGGL((gemm_kernel<BF16, false, true>), grid, block, 0, st, p);
+    if (p.fastA && p.fastB) {
+        if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_kernel<BF16, true, true, true>), grid, block, 0, st, p);
+        else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_kernel<BF16, true, false, true>), grid, block, 0, st, p);
+        else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<BF16, false, false, true>), grid, block, 0, st, p);
+        else                     hipLaunchKernelGGL((gemm_kernel<BF16, false, true, true>), grid, block, 0, st, p);
+    } else {
+        if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_kernel<BF16, true, true, false>), grid, block, 0, st, p);
+        else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_kernel<BF16, true, false, false>), grid, block, 0, st, p);
+        else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<BF16, false, false, false>), grid, block, 0, st, p);
+        else                     hipLaunchKernelGGL((gemm_kernel<BF16, false, true, false>), grid, block, 0, st, p);
+    }
     ASR_LAUNCH_CHECK("asr_gemm");
     return ASR_OK;
 }

@@ -50,6 +50,15 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* 
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = f2bf_bits(src[i]);
 }
 
+// i / n for 0 <= i < 2^22, n <= 2^10 through a float reciprocal (a runtime integer division costs ~40 VALU instructions;
+// the index maps of the staging loops do a dozen of them per thread per launch)
+__device__ __forceinline__ int fdiv(int i, int n, float inv) {
+    int q = (int)((float)i * inv);
+    const int r = i - q * n;
+    q += (r >= n) - (r < 0);
+    return q;
+}
+
 struct DecP {
     asr_dec_dims_t d;
     asr_dec_weights_t w;
@@ -178,7 +187,8 @@ __global__ __launch_bounds__(512) void att_energy_kernel(DecP p, int t) {
     auto ld_wc = [&](int i) { return p.w.Wconv[i]; };
     auto st_wc = [&](int i, float v) { s_wc[i] = v; };
     auto ld_wp = [&](int i) { return p.w.Wproj[i]; };
-    auto st_wp = [&](int i, float v) { const int a = i / d.Kn, k = i - a * d.Kn; s_wp[k * d.A + a] = v; };
+    const float inv_kn = 1.f / (float)d.Kn;
+    auto st_wp = [&](int i, float v) { const int a = fdiv(i, d.Kn, inv_kn), k = i - a * d.Kn; s_wp[k * d.A + a] = v; };
     Stage<2> g_pa; Stage<4> g_wc; Stage<6> g_wp;
     g_pa.v[0] = g_pa.v[1] = 0.f;
     if (prev) g_pa.load(win, tid, 512, ld_pa);
@@ -212,8 +222,9 @@ __global__ __launch_bounds__(512) void att_energy_kernel(DecP p, int t) {
         const int ngrp = TE / 4, nout = d.Kn * ngrp;
         const int parts = max(1, min(8, 512 / nout));
         const int tp = (taps + parts - 1) / parts;
+        const float inv_nout = 1.f / (float)nout;
         for (int it = tid; it < parts * nout; it += 512) {
-            const int pz = it / nout, o = it - pz * nout, k = o / ngrp, ig = o - k * ngrp;
+            const int pz = fdiv(it, nout, inv_nout), o = it - pz * nout, k = o / ngrp, ig = o - k * ngrp;   // ngrp is a constant
             const int j0 = pz * tp, j1 = min(taps, j0 + tp);
             const float* wk = s_wc + k * taps;
             const float* pa = s_pa + 4 * ig;
@@ -601,10 +612,11 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
     auto ld_cx = [&](int e) { return p.f.s.xin[row * XW + d.Dd + e]; };
     auto ld_at = [&](int i) { return att[i]; };
     auto ld_dn = [&](int i) { return dnext[i]; };
-    auto ld_cv = [&](int i) { const int k = i / TE, ti = i - k * TE; return convrow[(long)k * d.Tp + min(tau0 + ti, d.Tp - 1)]; };
-    auto st_cv = [&](int i, float v) { const int k = i / TE, ti = i - k * TE; s_cv[ti * KP + k] = (tau0 + ti < d.Tp) ? v : 0.f; };
+    const float inv_te = 1.f / (float)TE, inv_kn = 1.f / (float)d.Kn;
+    auto ld_cv = [&](int i) { const int k = fdiv(i, TE, inv_te), ti = i - k * TE; return convrow[(long)k * d.Tp + min(tau0 + ti, d.Tp - 1)]; };
+    auto st_cv = [&](int i, float v) { const int k = fdiv(i, TE, inv_te), ti = i - k * TE; s_cv[ti * KP + k] = (tau0 + ti < d.Tp) ? v : 0.f; };
     auto ld_wp = [&](int i) { return p.f.w.Wproj[i]; };
-    auto st_wp = [&](int i, float v) { const int a_ = i / d.Kn, k = i - a_ * d.Kn; s_wpT[k * AP + a_] = v; };
+    auto st_wp = [&](int i, float v) { const int a_ = fdiv(i, d.Kn, inv_kn), k = i - a_ * d.Kn; s_wpT[k * AP + a_] = v; };
     Stage<2> g_dc, g_cx, g_at, g_dn, g_cv; Stage<6> g_wp;
     g_dc.load(d.E, tid, nthr, ld_dc);
     g_cx.load(d.E, tid, nthr, ld_cx);
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
     }
     // ---- stage 3: dconv[tau,k] = sum_a dl[tau,a] * W_proj[a,k]  (thread per (frame, k), float4 over a)
     for (int o = tid; o < TE * d.Kn; o += nthr) {
-        const int f = o % TE, k = o / TE;
+        const int k = fdiv(o, TE, inv_te), f = o - k * TE;
         const float4* dl4 = reinterpret_cast<const float4*>(s_dl + f * AP);
         const float4* w4 = reinterpret_cast<const float4*>(s_wpT + k * AP);
         float v0 = 0.f, v1 = 0.f;

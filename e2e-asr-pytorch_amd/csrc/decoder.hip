@@ -1099,6 +1099,15 @@ void launch_energy(const DecP& p, int t, const EnergyPlan& pl, hipStream_t st) {
 
 }  // namespace
 
+// decoder_persist.hip
+size_t dec_fwd_persist_work_bytes(const asr_dec_dims_t& d);
+int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const float* enc,
+                       const int64_t* enc_len, void* work, size_t work_bytes, hipStream_t st);
+
+extern "C" size_t asr_att_decoder_fwd_work_bytes(const asr_dec_dims_t* dims) {
+    return dims ? dec_fwd_persist_work_bytes(*dims) : 0;
+}
+
 extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights,
                                    const float* enc, const int64_t* enc_len, const int64_t* teacher, int teacher_ld,
                                    const asr_dec_state_t* state, int prec, asr_stream_t stream) {
@@ -1130,7 +1139,14 @@ extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_wei
 
     const EnergyPlan epl = energy_plan(d);
     ASR_REQUIRE(epl.lds <= 64 * 1024, ASR_E_UNSUPPORTED, "asr_att_decoder_fwd: energy tile needs %zu B of LDS", epl.lds);
-    for (int t = 0; t < d.L; ++t) {
+    int t_begin = 0;
+    if (teacher && bf && state->work) {
+        // the whole teacher-forced loop as one persistent launch (decoder_persist.hip) when the shape has a plan
+        rc = dec_fwd_persistent(d, *weights, *state, enc, enc_len, state->work, state->work_bytes, st);
+        if (rc < 0) return rc;
+        if (rc == ASR_OK) t_begin = d.L;
+    }
+    for (int t = t_begin; t < d.L; ++t) {
         if (!teacher)
             hipLaunchKernelGGL(embed_kernel, dim3(cdiv((long)d.B * d.Dd, 256)), dim3(256), 0, st, weights->emb, state->tokens,
                                state->xin, d.B, d.L, d.Dd, XW, t, 1, d.V);

@@ -292,6 +292,10 @@ def att_decoder_forward(model, enc, enc_len, L, teacher, prec):
     B, Tp, _ = enc.shape
     d = _dec_dims(model, B, Tp, L)
     st = _dec_state(d, enc.device, half_copies=(prec == H.BF16 and d.E % 4 == 0))
+    if prec == H.BF16 and teacher is not None:
+        nwork = int(H.lib().asr_att_decoder_fwd_work_bytes(ctypes.byref(d)))     # 0: no single-launch plan for this shape
+        if nwork:
+            st['work'] = torch.empty(nwork, dtype=torch.uint8, device=enc.device)
     w = H.dec_weights_struct(_dec_tensors(model, False), d.NL)
     s = H.dec_state_struct(st)
     t_ptr, t_ld = (None, 0)

@@ -31,7 +31,8 @@ class DecWeights(ctypes.Structure):
 
 
 class DecState(ctypes.Structure):
-    _fields_ = [(n, _vp) for n in ('key', 'att', 'q', 'xin', 'gates', 'cs', 'hs', 'logits', 'energy', 'conv', 'key16', 'enc16', 'tokens')]
+    _fields_ = ([(n, _vp) for n in ('key', 'att', 'q', 'xin', 'gates', 'cs', 'hs', 'logits', 'energy', 'conv', 'key16', 'enc16', 'work')]
+                + [('work_bytes', ctypes.c_size_t), ('tokens', _vp)])
 
 
 _P = ctypes.POINTER
@@ -84,6 +85,7 @@ _RESTYPES = {
     'asr_ctc_loss_workspace_bytes': (_sz, [_i, _i, _i]),
     'asr_fbank_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'asr_att_decoder_bwd_workspace_bytes': (_sz, [_P(DecDims)]),
+    'asr_att_decoder_fwd_work_bytes': (_sz, [_P(DecDims)]),
 }
 
 
@@ -273,6 +275,10 @@ def dec_weights_struct(tensors, nl):
 def dec_state_struct(tensors):
     s = DecState()
     for n, _ in DecState._fields_:
+        if n == 'work_bytes':
+            w = tensors.get('work')
+            s.work_bytes = int(w.numel() * w.element_size()) if w is not None else 0
+            continue
         t = tensors.get(n)
         setattr(s, n, t.data_ptr() if t is not None else None)
     return s

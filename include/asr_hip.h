@@ -188,6 +188,8 @@ typedef struct {        /* forward outputs / saved activations, caller-allocated
     float* conv;        /* (B,L,Kn,Tp) location-convolution output per step, kept for backward; may be NULL for inference */
     void* key16;        /* (B,Tp,A) bf16 working copy of key for the step kernels; NULL = read the fp32 tensor (fp32 mode) */
     void* enc16;        /* (B,Tp,E) bf16 working copy of enc, filled by asr_att_decoder_fwd; NULL = read enc */
+    void* work;         /* optional scratch (256B aligned, asr_att_decoder_fwd_work_bytes) enabling the single-launch forward */
+    size_t work_bytes;
     int64_t* tokens;    /* (B,L)      input token of each step (<sos>=0 first) */
 } asr_dec_state_t;
 
@@ -195,6 +197,8 @@ int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* wei
                         const float* enc, const int64_t* enc_len, const int64_t* teacher, int teacher_ld,
                         const asr_dec_state_t* state, int prec, asr_stream_t stream);
 size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims);
+/* bytes of state->work that let asr_att_decoder_fwd run the teacher-forced loop as ONE persistent launch (0: shape has no plan) */
+size_t asr_att_decoder_fwd_work_bytes(const asr_dec_dims_t* dims);
 /* dlogits (B,L,V) in; denc (B,Tp,E) accumulated (+=); parameter gradients accumulated into `grads`.
  * workspace must be 256B aligned. */
 int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights, const asr_dec_grads_t* grads,

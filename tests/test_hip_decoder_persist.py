@@ -1,0 +1,61 @@
+"""The single-launch (persistent, state-resident) decoder forward must reproduce the per-step kernels' saved state:
+same arithmetic up to summation order and the 1-ulp tag bits of the exchanged values (bf16 contraction mode)."""
+import ctypes
+import os
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg_name):
+    from src.asr import ASR
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'e2e-asr-pytorch_amd')
+    config = yaml.safe_load(open(os.path.join(root, 'config', cfg_name)))
+    torch.manual_seed(3)
+    return ASR(160, 31, 16, prec='bf16', seed=5, **config['model']).cuda().train()
+
+
+@pytest.mark.parametrize('B,Tp,L', [(16, 600, 12), (3, 170, 9), (9, 333, 7)])
+def test_persistent_forward_matches_step_kernels(B, Tp, L):
+    from src import hipabi as H
+    from src import functions as F
+    model = _model('librispeech_asr.yaml')
+    g = torch.Generator().manual_seed(B + Tp)
+    E = 640
+    enc = torch.tanh(torch.randn(B, Tp, E, generator=g)).cuda()
+    enc_len = torch.randint(max(Tp // 3, 1), Tp + 1, (B,), generator=g)
+    enc_len[0] = Tp
+    enc_len = enc_len.cuda()
+    teacher = torch.randint(2, 31, (B, L), generator=g).cuda()
+    d = F._dec_dims(model, B, Tp, L)
+    assert int(H.lib().asr_att_decoder_fwd_work_bytes(ctypes.byref(d))) > 0, 'no persistent plan for the reference shape'
+    _, st_p = F.att_decoder_forward(model, enc, enc_len, L, teacher, H.BF16)
+    assert st_p.get('work') is not None
+    torch.cuda.synchronize()
+    assert int(st_p['work'][:4].view(torch.int32).item()) == 0, 'persistent decoder raised its abort word'
+    orig = F._dec_state
+
+    def no_work(*a, **k):
+        s = orig(*a, **k)
+        return s
+    real = H.lib().asr_att_decoder_fwd_work_bytes
+    try:
+        H.lib().asr_att_decoder_fwd_work_bytes = lambda *_: 0
+        _, st_s = F.att_decoder_forward(model, enc, enc_len, L, teacher, H.BF16)
+    finally:
+        H.lib().asr_att_decoder_fwd_work_bytes = real
+    assert st_s.get('work') is None
+    torch.cuda.synchronize()
+    for name, tol in (('q', 2e-3), ('att', 2e-3), ('xin', 5e-3), ('hs', 5e-3), ('cs', 1e-2), ('gates', 5e-3), ('logits', 2e-2)):
+        a, b_ = st_p[name].float().cpu(), st_s[name].float().cpu()
+        assert torch.isfinite(a).all(), name
+        err = (a - b_).abs().max().item()
+        assert err < tol, '%s differs by %g' % (name, err)
+    # conv only where frames are valid (tiles past the utterance are not computed identically)
+    for bi in range(B):
+        n = int(enc_len[bi])
+        err = (st_p['conv'][bi, :, :, :n] - st_s['conv'][bi, :, :, :n]).abs().max().item()
+        assert err < 2e-3, 'conv row %d differs by %g' % (bi, err)

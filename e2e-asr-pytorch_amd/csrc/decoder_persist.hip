@@ -21,18 +21,34 @@
 #include "common.h"
 #include "handoff.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
-constexpr u64 PAIR_MASK = 1ull | (1ull << 32);
-__device__ __forceinline__ u64 pair_want(unsigned seq) { return (u64)(seq & 1u) | ((u64)(seq >> 1) << 32); }
-__device__ __forceinline__ u64 pack2(float a, float b, u64 want) {
-    return ((u64)(__float_as_uint(a) & ~1u) | ((u64)(__float_as_uint(b) & ~1u) << 32)) | want;
+// Tag = 6 bits in the three mantissa LSBs of both floats of a granule: 2-bit step sequence + 4-bit launch epoch.  (With a
+// 2-bit tag any stale or foreign 8 bytes pass the check with probability 1/4; recycled allocator memory whose old lines
+// still sit in this XCD's L2 did exactly that in the first step of a launch.)  Payload loses 3 of 24 mantissa bits.
+constexpr u64 PAIR_MASK = 7ull | (7ull << 32);
+__device__ __forceinline__ u64 pair_want(unsigned seq, unsigned epoch) {
+    const unsigned tag = ((epoch & 15u) << 2) | seq;
+    return (u64)(tag & 7u) | ((u64)(tag >> 3) << 32);
 }
-__device__ __forceinline__ float lo_f(u64 g) { return __uint_as_float((unsigned)g & ~1u); }
-__device__ __forceinline__ float hi_f(u64 g) { return __uint_as_float((unsigned)(g >> 32) & ~1u); }
+__device__ __forceinline__ u64 pack2(float a, float b, u64 want) {
+    return ((u64)(__float_as_uint(a) & ~7u) | ((u64)(__float_as_uint(b) & ~7u) << 32)) | want;
+}
+__device__ __forceinline__ float lo_f(u64 g) { return __uint_as_float((unsigned)g & ~7u); }
+__device__ __forceinline__ float hi_f(u64 g) { return __uint_as_float((unsigned)(g >> 32) & ~7u); }
 constexpr float NEG_BIG = -1e30f;       // masked energy in the exchange records (-inf would turn into NaN under the tag bit)
 constexpr int NCW = 8, NPW = 4;         // compute waves, polling waves
+#ifdef ASR_DIAG
+#define DP_DECL unsigned long long dg_t = __builtin_amdgcn_s_memrealtime(), dg_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DP_MARK(k) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); dg_acc[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); }
+#define DP_DUMP { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long* o = (unsigned long long*)p.status + 128; for (int k = 0; k < 16; ++k) o[k] = dg_acc[k]; } }
+#else
+#define DP_DECL
+#define DP_MARK(k)
+#define DP_DUMP
+#endif
 constexpr int RB = 5;                   // gate rows per batch of the cell contraction
 inline size_t align_up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -53,6 +69,7 @@ struct PD {
     int HG2, QG2, SG2;              // granules per producer record (even)
     int KC, KCP;                    // E + Dd, padded to a multiple of 8
     int allow_local;
+    unsigned epoch;                 // launch counter (tag bits)
 };
 
 // barrier among the NCW compute waves only (the polling waves are inside a spin loop at these points)
@@ -97,9 +114,21 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
     float* s_g = s_e + ((TE + 3) & ~3);                                               // [4*UPW]
     float* s_stage = s_g + ((4 * p.UPW + 3) & ~3);                                    // [NT][2*SG2]
     if (tid == 0) s_bar = 0u;
-    const bool local = xcd_consensus(reinterpret_cast<u64*>(p.status) + 64 + b, NT, p.allow_local, p.status);
     const long region = (long)NT * (p.HG2 + p.QG2 + p.SG2);
     auto xb = [&](int parity) { return p.xbuf + ((long)parity * d.B + b) * region; };
+    // The host memset reaches memory, but granules that an earlier launch stored L2-locally (sc0) can still sit in this
+    // XCD's L2 with perfectly valid tags (observed: wrong data in the first step after a launch with other inputs; a
+    // write-through `sc1` store of zeros did NOT displace the resident copy).  Every producer therefore clears its own
+    // records with the same L2-local store flavour before it joins the consensus - the barrier behind which polling starts.
+    for (int parity = 0; parity < 2; ++parity) {
+        u64* base = xb(parity);
+        for (int i = tid; i < p.HG2; i += blockDim.x) st_gran_local(base + (long)j * p.HG2 + i, 0ull);
+        for (int i = tid; i < p.QG2; i += blockDim.x) st_gran_local(base + (long)NT * p.HG2 + (long)j * p.QG2 + i, 0ull);
+        for (int i = tid; i < p.SG2; i += blockDim.x) st_gran_local(base + (long)NT * (p.HG2 + p.QG2) + (long)j * p.SG2 + i, 0ull);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool local = xcd_consensus(reinterpret_cast<u64*>(p.status) + 64 + b, NT, p.allow_local, p.status);
 
     // ---- resident data
     for (int i = tid; i < TE * A; i += blockDim.x) {
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             // H: h_{t-1} of the utterance -> s_x[E ..]
             if (t > 0) {
                 const u64* src = xb((t - 1) & 1);
-                const u64 want = pair_want(seq_of(t - 1));
+                const u64 want = pair_want(seq_of(t - 1), p.epoch);
                 for (int i0 = gt; 2 * i0 < NT * p.HG2; i0 += np) {
                     u64 lo[1], hi[1];
                     gather16<1>(src + 2 * i0, 0, 1, PAIR_MASK, want, lo, hi, p.status);
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             // Q: query of step t -> s_q
             {
                 const u64* src = xb(t & 1) + (long)NT * p.HG2;
-                const u64 want = pair_want(seq_of(t));
+                const u64 want = pair_want(seq_of(t), p.epoch);
                 for (int i0 = gt; 2 * i0 < NT * p.QG2; i0 += np) {
                     u64 lo[1], hi[1];
                     gather16<1>(src + 2 * i0, 0, 1, PAIR_MASK, want, lo, hi, p.status);
@@ -162,7 +191,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             // S: softmax records of all tiles -> s_stage (flat copy)
             {
                 const u64* src = xb(t & 1) + (long)NT * (p.HG2 + p.QG2);
-                const u64 want = pair_want(seq_of(t));
+                const u64 want = pair_want(seq_of(t), p.epoch);
                 const int npair = NT * p.SG2 / 2;
                 for (int i0 = gt; i0 < npair; i0 += 10 * np) {
                     u64 lo[10], hi[10];
@@ -190,11 +219,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
     const float bg = p.w.bg[0];
     float c_state = 0.f;                                                // cell state of unit u_base + lane (wave 0, lane < UPW)
     const int RPW = (4 * p.UPW + NCW - 1) / NCW;                        // gate rows per wave
+    DP_DECL
 
     for (int t = 0; t < L; ++t) {
         const long row = (long)b * L + t;
         float* s_x = s_x2 + (t & 1) * p.KCP;
-        const u64 want = pair_want(seq_of(t));
+        const u64 want = pair_want(seq_of(t), p.epoch);
         u64* out = xb(t & 1);
         // operands of the cell phase that do not depend on this step's hand-offs: requested now
         float add_r = 0.f;                                              // lane r of the wave: embproj + both biases of its gate row
@@ -208,7 +238,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                 }
             }
         }
+        DP_MARK(0)
         __syncthreads();                                                // B1: s_x holds h_{t-1}
+        DP_MARK(1)
         // ---- query slice: outputs q_base + o, two per wave per round, lanes over the reduction
         for (int o0 = 2 * wave; o0 < p.QPW; o0 += 2 * NCW) {
             float acc0 = 0.f, acc1 = 0.f;
@@ -242,20 +274,42 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             u64* dst = out + (long)NT * p.HG2 + (long)j * p.QG2 + p.QG2 - 1;
             if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
         }
-        // ---- location convolution of the tile from the previous attention row (runs while the query is gathered)
-        for (int o = tid; o < Kn * TE; o += 64 * NCW) {
-            const int k = o / TE, i = o - k * TE;
-            const float* wk = s_wc + k * taps;
-            const float* pa = s_attp + tau0 + i;                        // s_attp[Ks + tau] -> window start tau - Ks
-            float a0 = 0.f, a1 = 0.f;
-            int jj = 0;
-            for (; jj + 1 < taps; jj += 2) { a0 += wk[jj] * pa[jj]; a1 += wk[jj + 1] * pa[jj + 1]; }
-            if (jj < taps) a0 += wk[jj] * pa[jj];
-            const float v = a0 + a1;
-            s_conv[o] = v;
-            if (p.s.conv && tau0 + i < Tp) p.s.conv[(row * Kn + k) * Tp + tau0 + i] = v;
+        DP_MARK(2)
+        // ---- location convolution of the tile from the previous attention row (runs while the query is gathered):
+        //      item = (tap range, kernel, group of 4 frames) with a sliding register window, partial sums meet in LDS
+        {
+            constexpr int ngrp = TE / 4;
+            const int nout = Kn * ngrp;
+            const int parts = max(1, min(8, (64 * NCW) / nout));
+            const int tp = (taps + parts - 1) / parts;
+            float* s_part = s_stage;                                     // free until the S gather of this step
+            for (int it = tid; it < parts * nout; it += 64 * NCW) {
+                const int pz = it / nout, o = it - pz * nout, k = o / ngrp, ig = o - k * ngrp;
+                const int j0 = pz * tp, j1 = min(taps, j0 + tp);
+                const float* wk = s_wc + k * taps;
+                const float* pa = s_attp + tau0 + 4 * ig;                // pa[i + jj] = prev_att[tau0 + 4ig + i + jj - Ks]
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                float p0 = pa[j0], p1 = pa[j0 + 1], p2 = pa[j0 + 2];
+                for (int jj = j0; jj < j1; ++jj) {
+                    const float wv = wk[jj], p3 = pa[jj + 3];
+                    a0 += wv * p0; a1 += wv * p1; a2 += wv * p2; a3 += wv * p3;
+                    p0 = p1; p1 = p2; p2 = p3;
+                }
+                float* o4 = s_part + (long)pz * Kn * TE + k * TE + 4 * ig;
+                o4[0] = a0; o4[1] = a1; o4[2] = a2; o4[3] = a3;
+            }
+            compute_barrier(&s_bar, gen);
+            for (int o = tid; o < Kn * TE; o += 64 * NCW) {
+                float v = 0.f;
+                for (int pz = 0; pz < parts; ++pz) v += s_part[(long)pz * Kn * TE + o];
+                s_conv[o] = v;
+                const int k = o / TE, i = o - k * TE;
+                if (p.s.conv && tau0 + i < Tp) p.s.conv[(row * Kn + k) * Tp + tau0 + i] = v;
+            }
         }
+        DP_MARK(3)
         __syncthreads();                                                // B2: s_q holds q_t, s_conv the tile's conv
+        DP_MARK(4)
         // ---- energies of the tile: wave w owns frames w*TPW.., lanes sweep the attention dimension
         {
             float cv[KNMAX][TPW];
@@ -288,7 +342,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                 if (lane == 0) s_e[f] = (tau0 + f < len) ? (sv + bg) / d.temperature : NEG_BIG;
             }
         }
+        DP_MARK(5)
         compute_barrier(&s_bar, gen);                                   // c3: s_e complete
+        DP_MARK(6)
         // ---- local softmax statistics (every wave for itself) and the tile's partial context
         {
             const float ev = (lane < TE) ? s_e[lane] : NEG_BIG;
@@ -325,7 +381,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                 }
             }
         }
+        DP_MARK(7)
         __syncthreads();                                                // B3: s_stage holds every tile's record
+        DP_MARK(8)
         // ---- attention row and context of the utterance
         {
             float mi = NEG_BIG, si = 0.f;
@@ -351,7 +409,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                 if (c >= c_base && c < c_base + p.CPW) p.s.xin[row * XW + Dd + c] = acc;
             }
         }
+        DP_MARK(9)
         compute_barrier(&s_bar, gen);                                   // c5: s_x holds [ctx_t | h_{t-1}]
+        DP_MARK(10)
         // ---- LSTM cell: gate rows r = g*UPW + ul of this workgroup, RPW rows per wave, lanes over 16-byte chunks
         {
             const int nchunk = p.KCP >> 3;
@@ -398,7 +458,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             const int r = wave * RPW + lane;
             if (lane < RPW && r < 4 * p.UPW) s_g[r] = mine + add_r;
         }
+        DP_MARK(11)
         compute_barrier(&s_bar, gen);                                   // c6: s_g holds the gate pre-activations
+        DP_MARK(12)
         if (wave == 0) {
             const int unit = u_base + lane;
             const bool uok = lane < p.UPW && unit < Dd;
@@ -419,7 +481,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                 if (local) publish<true>(dst, pack2(hv, hn, want)); else publish<false>(dst, pack2(hv, hn, want));
             }
         }
+        DP_MARK(13)
     }
+    DP_DUMP
 }
 
 __global__ void build_wcat16_kernel(const float* __restrict__ wih, const float* __restrict__ whh, unsigned short* __restrict__ out,
@@ -457,7 +521,8 @@ PersistPlan persist_plan(const asr_dec_dims_t& d) {
     const int taps = 2 * d.Ks + 1;
     size_t fl = 0;
     fl += ((d.Kn * d.A + 3) & ~3) + 2 * pl.KCP + 2 * ((d.A + 3) & ~3) + ((d.Tp + 2 * d.Ks + 4 + 3) & ~3) + ((d.Kn * taps + 3) & ~3) +
-          (size_t)d.Kn * pl.TE + ((pl.TE + 3) & ~3) + ((4 * pl.UPW + 3) & ~3) + (size_t)pl.NT * 2 * pl.SG2;
+          (size_t)d.Kn * pl.TE + ((pl.TE + 3) & ~3) + ((4 * pl.UPW + 3) & ~3) +
+          std::max((size_t)pl.NT * 2 * pl.SG2, (size_t)8 * d.Kn * pl.TE);      // the record stage doubles as the conv's partial-sum area
     pl.lds = 2 * (size_t)(((pl.TE * d.A + 7) & ~7) + ((pl.TE * d.E + 7) & ~7)) + 4 * fl;
     if (pl.lds > 156 * 1024) return pl;
     pl.status_bytes = 4096;
@@ -494,9 +559,10 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
     int rc = asr_gemm(s.xin, w.Wih[0], embproj, nullptr, d.B * d.L, 4 * d.Dd, d.Dd, XW, XW, 4 * d.Dd, 1, 1, ASR_ACT_NONE, 0, 1, 1, 0, 0, 0,
                       0, 0, ASR_BF16, (asr_stream_t)st);
     if (rc != ASR_OK) return rc;
+    static unsigned epoch_counter = 1;
     static int allow = -1;
     if (allow < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); allow = (e && e[0] == '0') ? 0 : 1; }
-    PD p{d, w, s, enc, enc_len, wcat16, embproj, xbuf, status, pl.NT, pl.TE, pl.UPW, pl.QPW, pl.CPW, pl.HG2, pl.QG2, pl.SG2, pl.KC, pl.KCP, allow};
+    PD p{d, w, s, enc, enc_len, wcat16, embproj, xbuf, status, pl.NT, pl.TE, pl.UPW, pl.QPW, pl.CPW, pl.HG2, pl.QG2, pl.SG2, pl.KC, pl.KCP, allow, epoch_counter++};
     const int cpx = cdiv(d.B, 8);
     const dim3 grid(8 * cpx * pl.NT), block(64 * (NCW + NPW));
 #define DPF_LAUNCH(KN_, TPW_)                                                                                                   \

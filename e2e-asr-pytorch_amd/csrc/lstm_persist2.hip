@@ -51,6 +51,7 @@ struct P2 {
     int B, T, H, ND, P;
     int allow_local;     // 1: use XCD-local hand-offs when all workgroups of a direction share an XCD
     int poll_delay;      // the polling waves sleep this many x 128 clocks at the start of a step, while nothing can have been published yet
+    unsigned epoch;      // launch counter (tag bits)
 };
 // units of s_sleep(2) = 128 clocks: the first polling round of a step is started roughly when the producers' stores of that
 // step become visible (a round started earlier returns stale data and costs a full round trip, ~0.6 us under this traffic)
@@ -71,8 +72,12 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __built
 //                        stores / prefetches would not be seen before those have completed (measured: +1 us per step).
 // Exchange buffer xbuf[parity][dir][b][H/4].
 __host__ __device__ __forceinline__ long fwd_region(int B, int H) { return (long)B * (H >> 2); }   // granules per (parity, direction)
-constexpr u64 FWD_MASK = (1ull << 14) | (1ull << 30);
-__device__ __forceinline__ u64 fwd_want(unsigned seq) { return ((u64)(seq & 1u) << 14) | ((u64)(seq >> 1) << 30); }
+// tag: bit 14 of each of the four bf16 values (always 0 for |h| <= 1): step sequence in elements 0,1, launch epoch in 2,3
+// (the epoch keeps granules of an earlier launch, which can survive in an L2 with valid sequence bits, from being accepted)
+constexpr u64 FWD_MASK = (1ull << 14) | (1ull << 30) | (1ull << 46) | (1ull << 62);
+__device__ __forceinline__ u64 fwd_want(unsigned seq, unsigned epoch) {
+    return ((u64)(seq & 1u) << 14) | ((u64)(seq >> 1) << 30) | ((u64)(epoch & 1u) << 46) | ((u64)((epoch >> 1) & 1u) << 62);
+}
 
 template <int NKS>
 __global__ __launch_bounds__(512) void lstm_fwd_p2(P2 p) {
@@ -88,6 +93,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_p2(P2 p) {
     for (int i = tid; i < 2 * 16 * LD / 2; i += 512) reinterpret_cast<unsigned*>(smem)[i] = 0u;
     const int HG = H >> 2, total = B * HG;
     const long xregion = fwd_region(B, H);               // granules per (parity, direction)
+    // granules that an earlier launch stored L2-locally can still sit in this XCD's L2 with valid tags although the host
+    // memset has cleared memory: every producer clears its own granules with L2-local stores before it joins the
+    // consensus, which is the barrier behind which polling starts (see decoder_persist.hip)
+    for (int i = tid; i < 2 * B * 4; i += 512) {
+        const int parity = i / (B * 4), r = i - parity * (B * 4), bb = r >> 2, qq = r & 3;
+        if ((u0 >> 2) + qq < HG) st_gran_local(p.xbuf + ((long)parity * ND + d) * xregion + (long)bb * HG + (u0 >> 2) + qq, 0ull);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const bool local = xcd_consensus(reinterpret_cast<u64*>(p.abort_flag) + 24 + d, p.P, p.allow_local, p.abort_flag);
 
     if (tid >= 256) {
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_p2(P2 p) {
                 u64 glo[CH], ghi[CH];
                 for (int z = 0; z < p.poll_delay; ++z) __builtin_amdgcn_s_sleep(2);
                 const u64* src = p.xbuf + ((long)((s - 1) & 1) * ND + d) * xregion + 2 * gt;
-                const int sp = gather16<CH>(src, 512, cnt, FWD_MASK, fwd_want(seq_of(s - 1)), glo, ghi, p.abort_flag);
+                const int sp = gather16<CH>(src, 512, cnt, FWD_MASK, fwd_want(seq_of(s - 1), p.epoch), glo, ghi, p.abort_flag);
                 DIAG2_MARK(0)
                 DIAG2_COUNT(7, sp)
 #pragma unroll
@@ -203,11 +217,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_p2(P2 p) {
                 // bit 14 of a bf16 is clear for every |x| < 2; clearing it (only NaN/Inf are affected, and those
                 // still reach the loss through y) keeps the sequence bits (bits 14 and 30 of the granule) intact
                 const u64 b0 = f2bf_bits(o_h.x) & 0xBFFFu, b1 = f2bf_bits(o_h.y) & 0xBFFFu;
-                const u64 b2 = f2bf_bits(o_h.z), b3 = f2bf_bits(o_h.w);
+                const u64 b2 = f2bf_bits(o_h.z) & 0xBFFFu, b3 = f2bf_bits(o_h.w) & 0xBFFFu;
                 const u64 v = b0 | (b1 << 16) | (b2 << 32) | (b3 << 48);
                 u64* dst = p.xbuf + ((long)(s & 1) * ND + d) * xregion + n * HG + (u0 >> 2) + q;
-                if (local) publish<true>(dst, v | fwd_want(seq_of(s)));
-                else publish<false>(dst, v | fwd_want(seq_of(s)));
+                if (local) publish<true>(dst, v | fwd_want(seq_of(s), p.epoch));
+                else publish<false>(dst, v | fwd_want(seq_of(s), p.epoch));
             }
 #ifndef ASR_NOIO
             if (bok) {
@@ -236,8 +250,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_p2(P2 p) {
 // Waves 0-3: cell backward, MFMA, publish, bulk traffic.  Waves 4-7: poll and sum the producers' partials
 // (wave 4+k sums producers [k*NTO, (k+1)*NTO)).
 // Exchange buffer xbuf[parity][dir][consumer][producer][b][8 pairs of fp32].
-constexpr u64 BWD_MASK = 1ull | (1ull << 32);
-__device__ __forceinline__ u64 bwd_want(unsigned seq) { return (u64)(seq & 1u) | ((u64)(seq >> 1) << 32); }
+// tag: three mantissa LSBs of both floats = 2-bit step sequence + 4-bit launch epoch
+constexpr u64 BWD_MASK = 7ull | (7ull << 32);
+__device__ __forceinline__ u64 bwd_want(unsigned seq, unsigned epoch) {
+    const unsigned tag = ((epoch & 15u) << 2) | seq;
+    return (u64)(tag & 7u) | ((u64)(tag >> 3) << 32);
+}
 
 template <int NTO>
 __global__ __launch_bounds__(512) void lstm_bwd_p2(P2 p) {
@@ -250,6 +268,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_p2(P2 p) {
     constexpr int LD = 72;
     for (int i = tid; i < 16 * LD / 2; i += 512) reinterpret_cast<unsigned*>(tile)[i] = 0u;
     const long per_par = (long)ND * P * P * B * 8;
+    // clear this producer's granules in the L2 (see lstm_fwd_p2): [parity][dir][consumer][me][b][8]
+    for (int i = tid; i < 2 * P * B * 8; i += 512) {
+        const int parity = i / (P * B * 8), r = i - parity * (P * B * 8), pc = r / (B * 8), rr = r - pc * (B * 8);
+        st_gran_local(p.xbuf + (long)parity * per_par + (long)d * P * P * B * 8 + (((long)pc * P + me) * B * 8) + rr, 0ull);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const bool local = xcd_consensus(reinterpret_cast<u64*>(p.abort_flag) + 24 + d, P, p.allow_local, p.abort_flag);
 
     if (tid >= 256) {
@@ -265,14 +290,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_p2(P2 p) {
                     for (int z = 0; z < p.poll_delay; ++z) __builtin_amdgcn_s_sleep(2);
                     const u64* src = p.xbuf + (long)((s - 1) & 1) * per_par + (((long)d * P + me) * P + pp_lo) * B * 8 + gb * 8 + 2 * g4;
                     u64 glo[NTO], ghi[NTO];
-                    gather16<NTO>(src, (long)B * 8, cntp, BWD_MASK, bwd_want(seq_of(s - 1)), glo, ghi, p.abort_flag);
+                    gather16<NTO>(src, (long)B * 8, cntp, BWD_MASK, bwd_want(seq_of(s - 1), p.epoch), glo, ghi, p.abort_flag);
 #pragma unroll
                     for (int i = 0; i < NTO; ++i)
                         if (i < cntp) {
-                            a0 += __uint_as_float((unsigned)glo[i] & ~1u);
-                            a1 += __uint_as_float((unsigned)(glo[i] >> 32) & ~1u);
-                            a2 += __uint_as_float((unsigned)ghi[i] & ~1u);
-                            a3 += __uint_as_float((unsigned)(ghi[i] >> 32) & ~1u);
+                            a0 += __uint_as_float((unsigned)glo[i] & ~7u);
+                            a1 += __uint_as_float((unsigned)(glo[i] >> 32) & ~7u);
+                            a2 += __uint_as_float((unsigned)ghi[i] & ~7u);
+                            a3 += __uint_as_float((unsigned)(ghi[i] >> 32) & ~7u);
                         }
                 }
                 DIAG2_MARK(0)
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_p2(P2 p) {
             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(tile + n * LD + 8 * q);
             const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(tile + n * LD + 32 + 8 * q);
             u64* dst = p.xbuf + (long)(s & 1) * per_par + (long)d * P * P * B * 8;
-            const u64 want = bwd_want(seq_of(s));
+            const u64 want = bwd_want(seq_of(s), p.epoch);
             f32x4 acc[NTO];
 #pragma unroll
             for (int ot = 0; ot < NTO; ++ot) {
@@ -398,8 +423,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_p2(P2 p) {
                 const int tcol = wave + 4 * ot;
                 if (tcol < P && n < B) {
                     u64* o = dst + (((long)tcol * P + me) * B + n) * 8 + 2 * q;
-                    const u64 v0 = (u64)(__float_as_uint(acc[ot][0]) & ~1u) | ((u64)(__float_as_uint(acc[ot][1]) & ~1u) << 32);
-                    const u64 v1 = (u64)(__float_as_uint(acc[ot][2]) & ~1u) | ((u64)(__float_as_uint(acc[ot][3]) & ~1u) << 32);
+                    const u64 v0 = (u64)(__float_as_uint(acc[ot][0]) & ~7u) | ((u64)(__float_as_uint(acc[ot][1]) & ~7u) << 32);
+                    const u64 v1 = (u64)(__float_as_uint(acc[ot][2]) & ~7u) | ((u64)(__float_as_uint(acc[ot][3]) & ~7u) << 32);
                     if (local) { publish<true>(o, v0 | want); publish<true>(o + 1, v1 | want); }
                     else { publish<false>(o, v0 | want); publish<false>(o + 1, v1 | want); }
                 }
@@ -440,6 +465,7 @@ int poll_delay(bool bwd) {
     }
     return bwd ? db : df;
 }
+unsigned next_epoch() { static unsigned e = 1; return e++; }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -465,7 +491,7 @@ int lstm_fwd_persistent2(float* gates, const float* whh, const float* bias2, flo
     const size_t need = 256 + 2 * (size_t)ND * fwd_region(B, H) * sizeof(u64);
     if (ws_bytes < need) return 1;
     hipMemsetAsync(ws, 0, need, st);
-    P2 p{gates, whh, bias2, y, c, (u64*)((char*)ws + 256), (unsigned*)ws, B, T, H, ND, H / 16, allow_local(), poll_delay(false)};
+    P2 p{gates, whh, bias2, y, c, (u64*)((char*)ws + 256), (unsigned*)ws, B, T, H, ND, H / 16, allow_local(), poll_delay(false), next_epoch()};
     const int nks = (H + 31) / 32;
     FWD2_CASE(1) FWD2_CASE(2) FWD2_CASE(4) FWD2_CASE(6) FWD2_CASE(8) FWD2_CASE(10) FWD2_CASE(12) FWD2_CASE(16)
     return 1;
@@ -479,7 +505,7 @@ int lstm_bwd_persistent2(float* gates, const float* whh, const float* dy, const 
     if (ws_bytes < need) return 1;
     hipMemsetAsync(ws, 0, need, st);
     P2 p{gates, whh, nullptr, const_cast<float*>(dy), const_cast<float*>(c), (u64*)((char*)ws + 256), (unsigned*)ws,
-         B, T, H, ND, (int)P, allow_local(), poll_delay(true)};
+         B, T, H, ND, (int)P, allow_local(), poll_delay(true), next_epoch()};
     const int nto = ((int)P + 3) / 4;
     BWD2_CASE(1) BWD2_CASE(2) BWD2_CASE(3) BWD2_CASE(4) BWD2_CASE(5) BWD2_CASE(6) BWD2_CASE(8)
     return 1;

@@ -791,10 +791,10 @@ __global__ __launch_bounds__(640) void att_bwd_energy_kernel(DecB p, int t, int 
 //   datt_next[tau'] = sum_k sum_j W[k][j] * dconv[k][tau' - j + Ks]      (dconv = this step's rows of state.conv)
 // grid (ceil(T'/TC), B), 512 threads; item = (tap range, k, group of 4 outputs) with a sliding register window.
 // (d W_conv needs no place in the sequential chain: wconv_grad_kernel after the loop.)
-__global__ __launch_bounds__(512) void att_bwd_conv_kernel(DecB p, int t, int TC) {
+__device__ __forceinline__ void att_bwd_conv_body(const DecB& p, int t, int TC, int bx, int by) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const asr_dec_dims_t& d = p.f.d;
-    const int b = blockIdx.y, tau0 = blockIdx.x * TC, tid = threadIdx.x;
+    const int b = by, tau0 = bx * TC, tid = threadIdx.x;
     const int taps = 2 * d.Ks + 1, win = TC + 2 * d.Ks;
     float* s_wc = smem_f;                                // [Kn*taps]
     float* s_dc = s_wc + ((d.Kn * taps + 3) & ~3);       // [Kn][win+4]  dconv window tau0-Ks .. tau0+TC+Ks
@@ -895,14 +895,14 @@ __global__ __launch_bounds__(512) void wconv_grad_kernel(DecP p, float* __restri
 
 // B4: query backward.  dq[b,t,:] already holds the gradient wrt the query pre-activation;  dhs[b,t-1,:] += dq * W_q.
 template <bool BF16>
-__global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t, int fuse_elem) {
+__device__ __forceinline__ void dec_query_bwd_body(const DecB& p, int t, int fuse_elem, int qblock) {
     // fuse_elem (single-layer decoders): dhs[b,t-1,:] is complete once this kernel has added its part, so the same
     // thread goes on with the cell backward of step t-1 for its (row, unit) - the elementwise kernel of that step and
     // its launch boundary are saved.  Operands of that epilogue are requested before the contraction.
     __shared__ float red[4][256];
     const asr_dec_dims_t& d = p.f.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
-    const int c = blockIdx.x * 16 + n;
+    const int c = qblock * 16 + n;
     const bool cok = c < d.Q;
     const float* wrow = p.wqT + (long)(cok ? c : 0) * d.A;
     for (int m0 = 0; m0 < d.B; m0 += 16) {
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t, int f
         const bool rok = ab < d.B;
         const float* drow = p.dq + ((long)(rok ? ab : 0) * d.L + t) * d.A;
         const int row = tid >> 4, col = tid & 15;
-        const int b = m0 + row, cc = blockIdx.x * 16 + col;
+        const int b = m0 + row, cc = qblock * 16 + col;
         const bool ook = b < d.B && cc < d.Q;
         const long ri = (long)(ook ? b : 0) * d.L + (t - 1);
         float* dh = p.dhs + ri * d.Q + (ook ? cc : 0);
@@ -944,6 +944,19 @@ __global__ __launch_bounds__(256) void dec_query_bwd_kernel(DecB p, int t, int f
             }
         }
         __syncthreads();
+    }
+}
+
+// B3 + B4 in one launch: the location-conv gradient and the query backward both consume the attention backward's outputs
+// and do not depend on each other, so their workgroups share a launch (one dependent kernel boundary per step less; the
+// launch lasts as long as the longer of the two).  blockIdx.x < nconv: conv tile (bx, by); else query block.
+template <bool BF16>
+__global__ __launch_bounds__(512) void att_bwd_tail_kernel(DecB p, int t, int TC, int gx, int nconv, int fuse_elem) {
+    if ((int)blockIdx.x < nconv) {
+        att_bwd_conv_body(p, t, TC, blockIdx.x % gx, blockIdx.x / gx);
+    } else {
+        if (threadIdx.x >= 256) return;                 // the matvec body is written for 4 waves
+        dec_query_bwd_body<BF16>(p, t, fuse_elem, blockIdx.x - nconv);
     }
 }
 
@@ -1281,7 +1294,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     ASR_REQUIRE(state->conv, ASR_E_ARG, "asr_att_decoder_bwd: state->conv (saved location convolution) is NULL");
     ASR_REQUIRE(nw_e * lay.NG <= 10, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: attention dim %d > 640", d.A);
     ASR_REQUIRE(d.Kn * ((taps + 3) / 4) <= 2048, ASR_E_UNSUPPORTED, "asr_att_decoder_bwd: location filter bank %d x %d too large", d.Kn, taps);
-    ASR_REQUIRE(lay.lds_e <= 150 * 1024 && lay.lds_c <= 150 * 1024 && lay.lds_w <= 150 * 1024, ASR_E_UNSUPPORTED,
+    ASR_REQUIRE(lay.lds_e <= 150 * 1024 && lay.lds_c <= 148 * 1024 && lay.lds_w <= 150 * 1024, ASR_E_UNSUPPORTED,
                 "asr_att_decoder_bwd: shape needs %zu / %zu / %zu B of LDS", lay.lds_e, lay.lds_c, lay.lds_w);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1291,7 +1304,9 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         hipFuncSetAttribute((const void*)att_bwd_energy_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         hipFuncSetAttribute((const void*)att_bwd_energy_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         hipFuncSetAttribute((const void*)att_bwd_energy_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        hipFuncSetAttribute((const void*)att_bwd_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        // (4 KB of static LDS of the query part count against the 160 KB)
+        hipFuncSetAttribute((const void*)att_bwd_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+        hipFuncSetAttribute((const void*)att_bwd_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
         hipFuncSetAttribute((const void*)wconv_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_set = true;
     }
@@ -1319,9 +1334,9 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         }
         if (t > 0) {
             // the location path reaches attn_{t-1}; step 0 convolves the constant initial attention
-            hipLaunchKernelGGL(att_bwd_conv_kernel, grid_c, dim3(512), lay.lds_c, st, p, t, lay.TC);
-            if (bf) hipLaunchKernelGGL(dec_query_bwd_kernel<true>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t, fuse);
-            else    hipLaunchKernelGGL(dec_query_bwd_kernel<false>, dim3(cdiv(d.Q, 16)), dim3(256), 0, st, p, t, fuse);
+            const int nconv = (int)(grid_c.x * grid_c.y), nq = cdiv(d.Q, 16);
+            if (bf) hipLaunchKernelGGL(att_bwd_tail_kernel<true>, dim3(nconv + nq), dim3(512), lay.lds_c, st, p, t, lay.TC, (int)grid_c.x, nconv, fuse);
+            else    hipLaunchKernelGGL(att_bwd_tail_kernel<false>, dim3(nconv + nq), dim3(512), lay.lds_c, st, p, t, lay.TC, (int)grid_c.x, nconv, fuse);
         }
     }
     ASR_LAUNCH_CHECK("asr_att_decoder_bwd");

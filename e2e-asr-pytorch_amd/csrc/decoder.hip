@@ -1000,8 +1000,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+size_t dec_bwd_persist_work_bytes_fw(const asr_dec_dims_t& d);
+int dec_bwd_persist_tiles_fw(const asr_dec_dims_t& d);
 struct BwdLayout {
-    size_t dhs, dxin, dq, dkey, datt_next, dcf, wq_t, slots, wslots, dkeypre, wcat[ASR_MAX_DEC_LAYERS], total;
+    size_t dhs, dxin, dq, dkey, datt_next, dcf, wq_t, slots, wslots, dkeypre, wcat[ASR_MAX_DEC_LAYERS], pwork, pwork_bytes, total;
+    int ntp;                // tiles per utterance of the persistent backward (0: no plan)
     int nte, slot;          // energy-backward tiles per utterance, floats per slot
     int TE, NG;             // frames per energy-backward workgroup, frame groups
     int TC;                 // outputs per conv-backward workgroup
@@ -1056,7 +1059,10 @@ BwdLayout bwd_layout(const asr_dec_dims_t& d) {
     o.datt_next = take((size_t)d.B * d.Tp);
     o.dcf = take((size_t)d.NL * d.B * d.Dd);
     o.wq_t = take((size_t)d.Q * d.A);
-    o.slots = take((size_t)d.B * o.nte * o.slot);
+    o.ntp = dec_bwd_persist_tiles_fw(d);
+    o.slots = take((size_t)d.B * (o.nte > o.ntp ? o.nte : o.ntp) * o.slot);
+    o.pwork_bytes = dec_bwd_persist_work_bytes_fw(d);
+    o.pwork = take(o.pwork_bytes / sizeof(float) + 64);
     o.wslots = take((size_t)d.B * o.nch * d.Kn * taps);
     for (int l = 0; l < d.NL; ++l) o.wcat[l] = take((size_t)((l == 0 ? XW : d.Dd) + d.Dd) * 4 * d.Dd);
     o.total = off;
@@ -1116,6 +1122,14 @@ void launch_energy(const DecP& p, int t, const EnergyPlan& pl, hipStream_t st) {
 size_t dec_fwd_persist_work_bytes(const asr_dec_dims_t& d);
 int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const float* enc,
                        const int64_t* enc_len, void* work, size_t work_bytes, hipStream_t st);
+
+size_t dec_bwd_persist_work_bytes(const asr_dec_dims_t& d);
+int dec_bwd_persist_tiles(const asr_dec_dims_t& d);
+namespace { size_t dec_bwd_persist_work_bytes_fw(const asr_dec_dims_t& d) { return dec_bwd_persist_work_bytes(d); }
+            int dec_bwd_persist_tiles_fw(const asr_dec_dims_t& d) { return dec_bwd_persist_tiles(d); } }
+int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const int64_t* enc_len,
+                       const float* dhs, float* dxin, float* dq, float* dkey, float* slots, int slot, const float* wcatT, const float* wqT,
+                       void* work, size_t work_bytes, hipStream_t st);
 
 extern "C" size_t asr_att_decoder_fwd_work_bytes(const asr_dec_dims_t* dims) {
     return dims ? dec_fwd_persist_work_bytes(*dims) : 0;
@@ -1228,6 +1242,12 @@ extern "C" int asr_att_decoder_step(const asr_dec_dims_t* dims, const asr_dec_we
     return ASR_OK;
 }
 
+// offset of the persistent backward's status block inside the workspace (diagnostics: tools/diag_dec.py)
+extern "C" size_t asr_att_decoder_bwd_status_offset(const asr_dec_dims_t* dims) {
+    if (!dims) return 0;
+    return bwd_layout(*dims).pwork;
+}
+
 extern "C" size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims) {
     if (!dims) return 0;
     return bwd_layout(*dims).total;
@@ -1267,7 +1287,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     hipMemsetAsync(p.dhs, 0, sizeof(float) * (size_t)BL * SW, st);
     hipMemsetAsync(p.dkey, 0, sizeof(float) * (size_t)d.B * d.Tp * d.A, st);
     hipMemsetAsync(p.dq, 0, sizeof(float) * (size_t)BL * d.A, st);
-    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * lay.nte * lay.slot, st);
+    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * (lay.nte > lay.ntp ? lay.nte : lay.ntp) * lay.slot, st);
 
     // transposed weights so that every per-step contraction is K-contiguous
     for (int l = 0; l < d.NL; ++l) {
@@ -1310,10 +1330,26 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         hipFuncSetAttribute((const void*)wconv_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         attr_set = true;
     }
+    int nslots_used = d.B * lay.nte;
+    bool looped = false;
+    if (bf && lay.ntp > 0 && state->enc16 && d.NL == 1) {
+        // the whole loop as one persistent, cluster-per-utterance launch (decoder_persist.hip)
+        rc = dec_bwd_persistent(d, *weights, *state, enc_len, p.dhs, p.dxin, p.dq, p.dkey, p.slots, lay.slot, p.wcatT[0], p.wqT,
+                                ws + lay.pwork, lay.pwork_bytes, st);
+        if (rc < 0) return rc;
+        if (rc == ASR_OK) {
+            looped = true;
+            nslots_used = d.B * lay.ntp;
+            // embedding part of dxin: dgates (B*L x 4Dd) . W_ih[:, :Dd]   (the context part was written by the kernel)
+            rc = asr_gemm(state->gates, weights->Wih[0], p.dxin, nullptr, BL, d.Dd, 4 * d.Dd, 4 * d.Dd, XW, XW, 1, 0, ASR_ACT_NONE, 0, 1, 1,
+                          0, 0, 0, 0, 0, prec, stream);
+            if (rc != ASR_OK) return rc;
+        }
+    }
     const dim3 grid_e(lay.nte, d.B), block_e(64 * nw_e * lay.NG);
     const bool h16 = state->key16 != nullptr && state->enc16 != nullptr && (d.E & 3) == 0;
     const dim3 grid_c(cdiv(d.Tp, lay.TC), d.B);
-    for (int t = d.L - 1; t >= 0; --t) {
+    for (int t = looped ? -1 : d.L - 1; t >= 0; --t) {
         const int last = (t == d.L - 1);
         const int fuse = (d.NL == 1) ? 1 : 0;    // the cell backward's elementwise part rides on the previous query backward
         for (int l = d.NL - 1; l >= 0; --l) {
@@ -1379,7 +1415,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     rc = asr_gemm(dkeypre, weights->Wk, denc, nullptr, M, d.E, d.A, d.A, d.E, d.E, 1, 0, ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, 0, 0, prec, stream);
     if (rc != ASR_OK) return rc;
     // slot partials -> d w_g, d W_proj, d b_g;  d W_conv from the saved dconv of every step
-    const int nslots = d.B * lay.nte;
+    const int nslots = nslots_used;
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->wg, 0, d.A, 0, 0);
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A * d.Kn, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wproj, d.A, d.A * d.Kn, d.A, d.Kn);
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(1), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->bg, d.A * (1 + d.Kn), 1, 0, 0);

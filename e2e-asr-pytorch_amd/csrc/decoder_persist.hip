@@ -23,6 +23,14 @@
 #include <stdlib.h>
 #include <algorithm>
 
+static int g_persist_fwd = -1, g_persist_bwd = -1;   // -1: from env ASR_DEC_PERSIST / ASR_DEC_PERSIST_BWD (default on)
+// bit 0: persistent forward, bit 1: persistent backward; returns the previous setting
+extern "C" int asr_att_decoder_set_persistent(int flags) {
+    const int old = (g_persist_fwd != 0 ? 1 : 0) | (g_persist_bwd != 0 ? 2 : 0);
+    g_persist_fwd = flags & 1; g_persist_bwd = (flags >> 1) & 1;
+    return old;
+}
+
 namespace {
 
 // Tag = 6 bits in the three mantissa LSBs of both floats of a granule: 2-bit step sequence + 4-bit launch epoch.  (With a
@@ -544,10 +552,9 @@ size_t dec_fwd_persist_work_bytes(const asr_dec_dims_t& d) {
 // Returns ASR_OK when the whole loop was launched, 1 when the configuration has no persistent plan, negative on error.
 int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const float* enc,
                        const int64_t* enc_len, void* work, size_t work_bytes, hipStream_t st) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("ASR_DEC_PERSIST"); enabled = (e && e[0] == '0') ? 0 : 1; }
+    if (g_persist_fwd < 0) { const char* e = getenv("ASR_DEC_PERSIST"); g_persist_fwd = (e && e[0] == '0') ? 0 : 1; }
     const PersistPlan pl = persist_plan(d);
-    if (!enabled || !pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv) return 1;
+    if (!g_persist_fwd || !pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv) return 1;
     char* base = (char*)work;
     unsigned* status = (unsigned*)base;
     u64* xbuf = (u64*)(base + pl.status_bytes);
@@ -579,5 +586,616 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
 #undef DPF_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { asr_set_error("asr_att_decoder_fwd(persistent): launch failed: %s", hipGetErrorString(e)); return ASR_E_LAUNCH; }
+    return ASR_OK;
+}
+
+// =================================================================================================
+// Backward of the teacher-forced decoder loop as ONE persistent launch (same cluster-per-utterance scheme as the
+// forward; bf16 mode, one decoder layer).  Resident per workgroup (tile j of utterance b) for all L steps: the key tile
+// (bf16, LDS), W_proj / W_conv, and IN REGISTERS the accumulators that the per-step kernels had to read-modify-write in
+// HBM every step: d w_g[a], d W_proj[a,:], the cell-state carry; the dkey tile is still read-modify-written, but in the L2 of
+// the XCD that owns the cluster (the same workgroup touches the same 48 KB every step).
+// Per step five all-gathers inside the cluster (tagged granules):
+//   G  gate-gradient rows of the workgroup's hidden units          -> every workgroup has dgates[4Dd]
+//   C  dctx slice (workgroup j owns CPW context columns)            -> every workgroup has dctx[E]
+//   Q  per-tile partial of the query gradient, V the tile's dconv   -> dq[A] (sum over tiles), dconv[Kn, T']
+//   N  the tile's gradient wrt the previous attention               -> datt_next[T'] for the next step
+// Waves 0..ncw-1 (ncw = ceil(A/64)) compute, three more waves only poll.
+// =================================================================================================
+namespace {
+
+constexpr int NPB = 3;            // polling waves of the backward kernel
+constexpr int NOUTW = 13;         // dctx / dh outputs per compute wave in the transposed-weight product
+
+struct PB {
+    asr_dec_dims_t d;
+    asr_dec_weights_t w;
+    asr_dec_state_t s;
+    const unsigned short* enc16;
+    const int64_t* enc_len;
+    const float* dhs;               // (B,L,Dd) gradient wrt h_t from the output layer
+    float* dxin;                    // (B,L,Dd+E)  context part written here
+    float* dq;                      // (B,L,A)     gradient wrt the query pre-activation
+    float* dkey;                    // (B,T',A)
+    float* slots;                   // (B*NT, slot)  d w_g [a], d W_proj [k][a], d b_g
+    const unsigned short* wcatT16;  // (Dd+E+Dd rows = input columns) x R4 bf16, row x = gradient weights of input column x
+    const float* wqT;               // (Dd x A)
+    u64* xbuf;
+    unsigned* status;
+    int slot, NT, UPW, CPW, R4;
+    int GG2, CG2, QG2, VG2, NG2;    // granules per producer record (even)
+    int allow_local;
+    unsigned epoch;
+};
+
+// LDS carve of dec_bwd_persist, shared by the kernel and the host plan (offsets in floats after the two bf16 tiles).
+struct BCarve { int AP, DW, shorts; int wpT, wc, dg, dctx, qst, dn, dcp, cv, de, out, dhn, pt, dcx, dq, gst, floats; };
+__host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn, int Ks, int NT, int UPW, int R4,
+                                            int GG2, int CG2, int QG2, int NG2) {
+    BCarve c;
+    int ap8 = (A + 7) >> 3; if ((ap8 & 1) == 0) ++ap8;
+    c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: 16-byte rows, odd in 16-byte units
+    c.DW = (NT * TE + 2 * Ks + 8 + 3) & ~3;             // zero-padded dconv row
+    c.shorts = ((TE * A + 7) & ~7) + TE * c.AP;
+    int o = 0;
+    c.wpT = o; o += Kn * c.AP;
+    c.wc = o; o += (Kn * (2 * Ks + 1) + 3) & ~3;
+    c.dg = o; o += R4;
+    c.dctx = o; o += NT * CG2 * 2;
+    c.qst = o; o += NT * QG2 * 2;
+    c.dn = o; o += NT * NG2 * 2 + 8;
+    c.dcp = o; o += Kn * c.DW;
+    c.cv = o; o += TE * KP;
+    c.de = o; o += (TE + 3) & ~3;
+    c.out = o; o += NOUTW * 8;
+    c.dhn = o; o += (UPW + 3) & ~3;
+    c.pt = o; o += 4 * Kn * TE;
+    c.dcx = o; o += (E + 3) & ~3;
+    c.dq = o; o += (A + 3) & ~3;
+    c.gst = o; o += NT * GG2 * 2;
+    c.floats = o;
+    return c;
+}
+
+__device__ __forceinline__ void cbar(unsigned* cnt, unsigned& gen, int nw) {
+    gen += nw;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// flat copy of one gathered exchange region into LDS (poll role): n16 16-byte pairs
+template <int CH>
+__device__ __forceinline__ void poll_copy(const u64* src, int n16, float* dst, int gt, int np, u64 want, unsigned* status) {
+    for (int i0 = gt; i0 < n16; i0 += CH * np) {
+        u64 lo[CH], hi[CH];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) if (i0 + k * np < n16) cnt = k + 1;
+        gather16<CH>(src + 2 * i0, 2 * np, cnt, PAIR_MASK, want, lo, hi, status);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k < cnt) *reinterpret_cast<float4*>(dst + 4 * (long)(i0 + k * np)) = make_float4(lo_f(lo[k]), hi_f(lo[k]), lo_f(hi[k]), hi_f(hi[k]));
+    }
+}
+
+template <int KNMAX, int TE>
+__global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned s_bar;
+    __shared__ float s_red[8];
+    constexpr int KP = (KNMAX + 3) & ~3;
+    const asr_dec_dims_t& d = p.d;
+    const int id = blockIdx.x, xcd = id & 7, slot_id = id >> 3;
+    const int cb = slot_id / p.NT, j = slot_id - cb * p.NT;
+    const int b = cb * 8 + xcd;
+    if (b >= d.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = p.NT, A = d.A, E = d.E, Dd = d.Dd, Tp = d.Tp, Kn = d.Kn, Ks = d.Ks, L = d.L;
+    const int ncw = (A + 63) >> 6, nct = 64 * ncw;                     // compute waves / threads
+    const int taps = 2 * Ks + 1, XW = Dd + E, R4 = p.R4;
+    const int tau0 = j * TE;
+    const int len = min((int)p.enc_len[b], Tp);
+    const int tmax = max(len - 1, 0);
+    const BCarve cv_ = bwd_carve(TE, KP, A, E, Kn, Ks, NT, p.UPW, R4, p.GG2, p.CG2, p.QG2, p.NG2);
+    const int AP = cv_.AP, DW = cv_.DW;
+    const int TW = NT * TE;                                             // padded attention row
+    // ---- LDS carve
+    unsigned short* s_key = reinterpret_cast<unsigned short*>(smem);                    // [TE][A] bf16
+    unsigned short* s_dl = s_key + ((TE * A + 7) & ~7);                                  // [TE][AP] bf16  d loc pre-activation
+    float* s_f = reinterpret_cast<float*>(s_key + cv_.shorts);
+    float* s_wpT = s_f + cv_.wpT;                                                        // [Kn][AP]
+    float* s_wc = s_f + cv_.wc;                                                          // [Kn*taps]
+    float* s_dg = s_f + cv_.dg;                                                          // [R4]    dgates of the utterance
+    float* s_dctx = s_f + cv_.dctx;                                                      // [NT*CG2*2] gathered dctx slices (flat records)
+    float* s_qst = s_f + cv_.qst;                                                        // [NT][QG2*2] dq partials
+    float* s_dn = s_f + cv_.dn;                                                          // [NT*NG2*2 + pad] datt_next (flat records = frames)
+    float* s_dcp = s_f + cv_.dcp;                                                        // [Kn][DW] zero-padded dconv rows (Ks + TW + Ks + pad)
+    float* s_cv = s_f + cv_.cv;                                                          // [TE][KP]
+    float* s_de = s_f + cv_.de;                                                          // [TE]
+    float* s_out = s_f + cv_.out;                                                        // [NOUTW * 8] products of P1, then scratch
+    float* s_dhn = s_f + cv_.dhn;                                                        // [UPW] dh carried to step t-1
+    float* s_pt = s_f + cv_.pt;                                                          // [4*Kn*TE] partial sums of datt_next (tap ranges)
+    float* s_dcx = s_f + cv_.dcx;                                                        // [E] dctx, contiguous
+    float* s_dq = s_f + cv_.dq;                                                          // [A] dq of the utterance
+    float* s_gst = s_f + cv_.gst;                                                        // [NT][GG2*2] gathered gate-gradient records
+    const long region = (long)NT * (p.GG2 + p.CG2 + p.QG2 + p.VG2 + p.NG2);
+    auto xb = [&](int parity) { return p.xbuf + ((long)parity * d.B + b) * region; };
+    const long offC = (long)NT * p.GG2, offQ = offC + (long)NT * p.CG2, offV = offQ + (long)NT * p.QG2, offN = offV + (long)NT * p.VG2;
+    if (tid == 0) s_bar = 0u;
+    // clear this producer's records in the L2 (see the forward kernel)
+    for (int parity = 0; parity < 2; ++parity) {
+        u64* base = xb(parity);
+        for (int i = tid; i < p.GG2; i += blockDim.x) st_gran_local(base + (long)j * p.GG2 + i, 0ull);
+        for (int i = tid; i < p.CG2; i += blockDim.x) st_gran_local(base + offC + (long)j * p.CG2 + i, 0ull);
+        for (int i = tid; i < p.QG2; i += blockDim.x) st_gran_local(base + offQ + (long)j * p.QG2 + i, 0ull);
+        for (int i = tid; i < p.VG2; i += blockDim.x) st_gran_local(base + offV + (long)j * p.VG2 + i, 0ull);
+        for (int i = tid; i < p.NG2; i += blockDim.x) st_gran_local(base + offN + (long)j * p.NG2 + i, 0ull);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool local = xcd_consensus(reinterpret_cast<u64*>(p.status) + 64 + b, NT, p.allow_local, p.status);
+
+    // ---- resident data
+    for (int i = tid; i < TE * A; i += blockDim.x) {
+        const int f = i / A, a = i - f * A;
+        s_key[i] = f2bf_bits(p.s.key[((long)b * Tp + min(tau0 + f, tmax)) * A + a]);
+    }
+    for (int i = tid; i < Kn * AP; i += blockDim.x) { const int k = i / AP, a = i - k * AP; s_wpT[i] = (a < A) ? p.w.Wproj[a * Kn + k] : 0.f; }
+    for (int i = tid; i < Kn * taps; i += blockDim.x) s_wc[i] = p.w.Wconv[i];
+    for (int i = tid; i < R4; i += blockDim.x) s_dg[i] = 0.f;
+    for (int i = tid; i < NT * p.NG2 * 2 + 8; i += blockDim.x) s_dn[i] = 0.f;
+    for (int i = tid; i < Kn * DW; i += blockDim.x) s_dcp[i] = 0.f;
+    for (int i = tid; i < TE * AP; i += blockDim.x) s_dl[i] = 0;
+    for (int i = tid; i < p.UPW; i += blockDim.x) s_dhn[i] = 0.f;
+    __syncthreads();
+
+    if (wave >= ncw) {
+        // =========================== polling role ===========================
+        const int gt = tid - nct, np = 64 * NPB;
+        for (int t = L - 1; t >= 0; --t) {
+            const int s = L - 1 - t;                                     // step counter of this launch (tags, parity)
+            const u64 want = pair_want(seq_of(s), p.epoch);
+            const u64* base = xb(s & 1);
+            poll_copy<4>(base, NT * p.GG2 / 2, s_gst, gt, np, want, p.status);
+            __syncthreads();                                            // H1
+            poll_copy<4>(base + offC, NT * p.CG2 / 2, s_dctx, gt, np, want, p.status);
+            __syncthreads();                                            // H2
+            poll_copy<8>(base + offQ, NT * p.QG2 / 2, s_qst, gt, np, want, p.status);
+            {   // dconv tiles go straight into the zero-padded per-kernel rows: s_dcp[k][Ks + prod*TE + f]
+                const int n16 = NT * p.VG2 / 2;
+                for (int i0 = gt; i0 < n16; i0 += 8 * np) {
+                    u64 lo[8], hi[8];
+                    int cnt = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (i0 + k * np < n16) cnt = k + 1;
+                    gather16<8>(base + offV + 2 * i0, 2 * np, cnt, PAIR_MASK, want, lo, hi, p.status);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < cnt) {
+                            const int g0 = 2 * (i0 + k * np), prod = g0 / p.VG2, r0 = 2 * (g0 - prod * p.VG2);
+                            const float v[4] = {lo_f(lo[k]), hi_f(lo[k]), lo_f(hi[k]), hi_f(hi[k])};
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                const int r = r0 + q4;
+                                if (r < Kn * TE) { const int kk = r / TE, f = r - kk * TE; s_dcp[kk * DW + Ks + prod * TE + f] = v[q4]; }
+                            }
+                        }
+                }
+            }
+            __syncthreads();                                            // H3
+            if (t > 0) poll_copy<4>(base + offN, NT * p.NG2 / 2, s_dn, gt, np, want, p.status);
+            __syncthreads();                                            // H4
+        }
+        return;
+    }
+
+    // =========================== compute role ===========================
+    unsigned gen = 0;
+    const int u_base = j * p.UPW, c_base = j * p.CPW;
+    const int a = tid;                                                  // attention column of this thread in the sweep
+    const bool aok = a < A;
+    const int ac = aok ? a : A - 1;
+    float wp[KNMAX], dwp[KNMAX];
+#pragma unroll
+    for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < Kn) ? p.w.Wproj[ac * Kn + k] : 0.f; dwp[k] = 0.f; }
+    const float wga = p.w.wg[ac];
+    float dwg = 0.f, dbg = 0.f, dc_carry = 0.f;
+    const int nout = p.CPW + p.UPW;
+    DP_DECL
+
+    for (int t = L - 1; t >= 0; --t) {
+        const int s = L - 1 - t;
+        const long row = (long)b * L + t;
+        const u64 want = pair_want(seq_of(s), p.epoch);
+        u64* out = xb(s & 1);
+        DP_MARK(0)
+        // ---- P0: cell backward of the workgroup's hidden units (wave 0), gate-gradient record
+        if (wave == 0) {
+            const int unit = u_base + lane;
+            const bool uok = lane < p.UPW && unit < Dd;
+            float dg4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (uok) {
+                float* g = p.s.gates + row * 4 * Dd + unit;
+                const float gi = g[0], gf = g[Dd], gg = g[2 * Dd], go = g[3 * Dd];
+                const float ct = p.s.cs[row * Dd + unit];
+                const float cp = (t > 0) ? p.s.cs[(row - 1) * Dd + unit] : 0.f;
+                const float dh = p.dhs[row * Dd + unit] + s_dhn[lane];
+                const float tc = tanhf(ct);
+                const float dc = dh * go * (1.f - tc * tc) + dc_carry;
+                dg4[0] = dc * gg * gi * (1.f - gi);
+                dg4[1] = dc * cp * gf * (1.f - gf);
+                dg4[2] = dc * gi * (1.f - gg * gg);
+                dg4[3] = dh * tc * go * (1.f - go);
+                dc_carry = dc * gf;
+                g[0] = dg4[0]; g[Dd] = dg4[1]; g[2 * Dd] = dg4[2]; g[3 * Dd] = dg4[3];
+            }
+            // record layout: local row r = g*UPW + ul; pairs (ul, ul+1) of the same gate by even lanes
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float nb = __shfl_down(dg4[g4], 1);
+                if ((lane & 1) == 0 && lane < ((p.UPW + 1) & ~1)) {
+                    u64* dst = out + (long)j * p.GG2 + ((g4 * ((p.UPW + 1) & ~1) + lane) >> 1);
+                    if (local) publish<true>(dst, pack2(dg4[g4], nb, want)); else publish<false>(dst, pack2(dg4[g4], nb, want));
+                }
+            }
+            if (lane == 0 && 4 * (((p.UPW + 1) & ~1) >> 1) < p.GG2) {
+                u64* dst = out + (long)j * p.GG2 + p.GG2 - 1;
+                if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
+            }
+        }
+        DP_MARK(1)
+        __syncthreads();                                                // H1: s_gst holds every workgroup's gate gradients
+        DP_MARK(2)
+        // scatter the records into the global row order of dgates: row = g*Dd + i*UPW + ul
+        {
+            const int UP2 = (p.UPW + 1) & ~1;
+            for (int i = tid; i < NT * 4 * UP2; i += nct) {
+                const int prod = i / (4 * UP2), r = i - prod * 4 * UP2, g4 = r / UP2, ul = r - g4 * UP2;
+                const int unit = prod * p.UPW + ul;
+                if (ul < p.UPW && unit < Dd) s_dg[g4 * Dd + unit] = s_gst[prod * p.GG2 * 2 + r];
+            }
+        }
+        cbar(&s_bar, gen, ncw);
+        DP_MARK(3)
+        // ---- P1: dctx slice and the recurrent part of dh_{t-1} for the own units: rows of [W_ih | W_hh]^T (bf16, L2) . dgates
+        {
+            float acc[NOUTW];
+            int xrow[NOUTW];
+#pragma unroll
+            for (int o = 0; o < NOUTW; ++o) {
+                acc[o] = 0.f;
+                const int oo = wave + ncw * o;
+                int x = 0;
+                if (oo < p.CPW) x = Dd + min(c_base + oo, E - 1);
+                else x = XW + min(u_base + (oo - p.CPW), Dd - 1);
+                xrow[o] = (oo < nout) ? x : Dd;
+            }
+            const int nchunk = R4 >> 3;
+            for (int ch0 = lane; ch0 < nchunk; ch0 += 64) {
+                uint4 wv[NOUTW];
+#pragma unroll
+                for (int o = 0; o < NOUTW; ++o) wv[o] = *reinterpret_cast<const uint4*>(p.wcatT16 + (long)xrow[o] * R4 + 8 * ch0);
+                const float4 ga = *reinterpret_cast<const float4*>(s_dg + 8 * ch0);
+                const float4 gb = *reinterpret_cast<const float4*>(s_dg + 8 * ch0 + 4);
+#pragma unroll
+                for (int o = 0; o < NOUTW; ++o) {
+                    const uint4 w4 = wv[o];
+                    acc[o] += __uint_as_float(w4.x << 16) * ga.x + __uint_as_float(w4.x & 0xffff0000u) * ga.y +
+                              __uint_as_float(w4.y << 16) * ga.z + __uint_as_float(w4.y & 0xffff0000u) * ga.w +
+                              __uint_as_float(w4.z << 16) * gb.x + __uint_as_float(w4.z & 0xffff0000u) * gb.y +
+                              __uint_as_float(w4.w << 16) * gb.z + __uint_as_float(w4.w & 0xffff0000u) * gb.w;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < NOUTW; ++o) {
+                const float sv = wave_sum(acc[o]);
+                const int oo = wave + ncw * o;
+                if (lane == 0 && oo < nout) s_out[oo] = sv;
+            }
+        }
+        cbar(&s_bar, gen, ncw);
+        {
+            // dctx slice record + global dxin (context part); recurrent dh for the next (earlier) step
+            const int CP2 = (p.CPW + 1) & ~1;
+            if (tid < CP2 / 2) {
+                const float v0 = (2 * tid < p.CPW && c_base + 2 * tid < E) ? s_out[2 * tid] : 0.f;
+                const float v1 = (2 * tid + 1 < p.CPW && c_base + 2 * tid + 1 < E) ? s_out[2 * tid + 1] : 0.f;
+                u64* dst = out + offC + (long)j * p.CG2 + tid;
+                if (local) publish<true>(dst, pack2(v0, v1, want)); else publish<false>(dst, pack2(v0, v1, want));
+                if (2 * tid < p.CPW && c_base + 2 * tid < E) p.dxin[row * XW + Dd + c_base + 2 * tid] = v0;
+                if (2 * tid + 1 < p.CPW && c_base + 2 * tid + 1 < E) p.dxin[row * XW + Dd + c_base + 2 * tid + 1] = v1;
+            } else if (tid == CP2 / 2 && CP2 / 2 < p.CG2) {
+                u64* dst = out + offC + (long)j * p.CG2 + p.CG2 - 1;
+                if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
+            }
+            if (tid < p.UPW) s_dhn[tid] = s_out[p.CPW + tid];
+        }
+        // operands of the sweep that do not depend on the hand-offs
+        const float qa = p.s.q[row * A + ac];
+        for (int i = tid; i < Kn * TE; i += nct) {
+            const int k = i / TE, f = i - k * TE;
+            s_cv[f * KP + k] = (tau0 + f < Tp) ? p.s.conv[(row * Kn + k) * Tp + tau0 + f] : 0.f;
+        }
+        DP_MARK(4)
+        __syncthreads();                                                // H2: s_dctx holds the dctx slices of all workgroups
+        DP_MARK(5)
+        // ---- P2: dattn of the tile, dot over the utterance, de
+        {
+            const int CG2f = 2 * p.CG2;
+            // the gathered slices as one contiguous vector (the records are CPW floats wide)
+            for (int e = tid; e < E; e += nct) { const int i = e / p.CPW; s_dcx[e] = s_dctx[i * CG2f + (e - i * p.CPW)]; }
+            cbar(&s_bar, gen, ncw);
+            auto dctx_at = [&](int e) { return s_dcx[e]; };
+            const int f = tid >> 3, part = tid & 7;
+            float v = 0.f;
+            if (f < TE) {
+                const unsigned short* er = p.enc16 + ((long)b * Tp + min(tau0 + f, tmax)) * E;
+                uint4 x[10];
+#pragma unroll
+                for (int u = 0; u < 10; ++u) x[u] = *reinterpret_cast<const uint4*>(er + 8 * min(part + 8 * u, (E >> 3) - 1));
+#pragma unroll
+                for (int u = 0; u < 10; ++u) {
+                    const int ch = part + 8 * u;
+                    if (8 * ch < E) {
+                        const int e0 = 8 * ch;
+                        v += __uint_as_float(x[u].x << 16) * dctx_at(e0) + __uint_as_float(x[u].x & 0xffff0000u) * dctx_at(e0 + 1) +
+                             __uint_as_float(x[u].y << 16) * dctx_at(e0 + 2) + __uint_as_float(x[u].y & 0xffff0000u) * dctx_at(e0 + 3) +
+                             __uint_as_float(x[u].z << 16) * dctx_at(e0 + 4) + __uint_as_float(x[u].z & 0xffff0000u) * dctx_at(e0 + 5) +
+                             __uint_as_float(x[u].w << 16) * dctx_at(e0 + 6) + __uint_as_float(x[u].w & 0xffff0000u) * dctx_at(e0 + 7);
+                    }
+                }
+            }
+            v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            float dot = 0.f;
+            for (int e = tid; e < E; e += nct) dot += dctx_at(e) * p.s.xin[row * XW + Dd + e];
+            if (t < L - 1) for (int tau = tid; tau < len; tau += nct) dot += p.s.att[row * Tp + tau] * s_dn[tau];
+            dot = wave_sum(dot);
+            if (lane == 0) s_red[wave] = dot;
+            cbar(&s_bar, gen, ncw);
+            dot = 0.f;
+            for (int w = 0; w < ncw; ++w) dot += s_red[w];
+            if (f < TE && part == 0) {
+                const int tau = tau0 + f;
+                const float dat = v + ((t < L - 1 && tau < TW) ? s_dn[min(tau, TW - 1)] : 0.f);
+                s_de[f] = (tau < len) ? p.s.att[row * Tp + tau] * (dat - dot) / d.temperature : 0.f;
+            }
+        }
+        cbar(&s_bar, gen, ncw);
+        DP_MARK(6)
+        // ---- P3: energy backward sweep; thread a owns column a of all TE frames
+        float dqa = 0.f;
+        // dkey tile: read-modify-write in global memory, which here means this XCD's L2 (the same workgroup touches the same
+        // 48 KB every step; a register-resident tile made the fully unrolled sweep spill ~800 registers)
+        float* dkp = p.dkey + ((long)b * Tp + tau0) * A + ac;
+#pragma unroll 1
+        for (int f0 = 0; f0 < TE; f0 += 8) {
+            float dk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dk[i] = dkp[(long)min(f0 + i, max(min(TE, len - tau0), 1) - 1) * A];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = f0 + i;
+                float cvv[KP];
+#pragma unroll
+                for (int k4 = 0; k4 < KP; k4 += 4) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(s_cv + f * KP + k4);
+                    cvv[k4] = c4.x; cvv[k4 + 1] = c4.y; cvv[k4 + 2] = c4.z; cvv[k4 + 3] = c4.w;
+                }
+                float lp = 0.f;
+#pragma unroll
+                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * cvv[k];
+                const float loc = tanh_f(lp);
+                const float u = tanh_f(bf2f_(s_key[f * A + ac]) + qa + loc);
+                const float de = s_de[f];
+                const float du = de * wga * (1.f - u * u);
+                const float dl = du * (1.f - loc * loc);
+                dwg += de * u;
+                dqa += du;
+#pragma unroll
+                for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * cvv[k];
+                if (aok && tau0 + f < len) dkp[(long)f * A] = dk[i] + du;
+                if (aok) s_dl[f * AP + a] = f2bf_bits(dl);
+            }
+        }
+        if (tid == 0) { for (int f = 0; f < TE; ++f) dbg += s_de[f]; }
+        // query-gradient partial of this tile, already times (1 - q^2): pairs (a, a+1) by even lanes
+        {
+            const float mine = aok ? dqa * (1.f - qa * qa) : 0.f;
+            const float nb = __shfl_down(mine, 1);
+            if ((lane & 1) == 0 && a < 2 * p.QG2) {
+                u64* dst = out + offQ + (long)j * p.QG2 + (a >> 1);
+                if (local) publish<true>(dst, pack2(mine, nb, want)); else publish<false>(dst, pack2(mine, nb, want));
+            }
+        }
+        cbar(&s_bar, gen, ncw);
+        DP_MARK(7)
+        // ---- P4: dconv[f][k] = sum_a dl[f][a] * W_proj[a][k]  (thread per (f, k))
+        for (int o = tid; o < TE * Kn; o += nct) {
+            const int k = o / TE, f = o - k * TE;
+            const unsigned short* dlr = s_dl + f * AP;
+            const float* wr = s_wpT + k * AP;
+            float v0 = 0.f, v1 = 0.f;
+            for (int x = 0; x < AP; x += 8) {
+                const uint4 d4 = *reinterpret_cast<const uint4*>(dlr + x);
+                const float4 wa = *reinterpret_cast<const float4*>(wr + x), wb = *reinterpret_cast<const float4*>(wr + x + 4);
+                v0 += __uint_as_float(d4.x << 16) * wa.x + __uint_as_float(d4.x & 0xffff0000u) * wa.y +
+                      __uint_as_float(d4.y << 16) * wa.z + __uint_as_float(d4.y & 0xffff0000u) * wa.w;
+                v1 += __uint_as_float(d4.z << 16) * wb.x + __uint_as_float(d4.z & 0xffff0000u) * wb.y +
+                      __uint_as_float(d4.w << 16) * wb.z + __uint_as_float(d4.w & 0xffff0000u) * wb.w;
+            }
+            const int tau = tau0 + f;
+            const float v = (tau < len) ? v0 + v1 : 0.f;
+            if (tau < Tp) p.s.conv[(row * Kn + k) * Tp + tau] = v;     // dconv over the saved conv (for d W_conv after the loop)
+            s_out[0] = 0.f;                                             // (keeps s_out initialised for the pad below)
+            // record order = [k][f]: pairs of frames
+            const float nb = __shfl_down(v, 1);
+            if ((f & 1) == 0) {
+                u64* dst = out + offV + (long)j * p.VG2 + (o >> 1);
+                if (local) publish<true>(dst, pack2(v, (f + 1 < TE) ? nb : 0.f, want)); else publish<false>(dst, pack2(v, (f + 1 < TE) ? nb : 0.f, want));
+            }
+        }
+        if (tid == 0 && (TE * Kn + 1) / 2 < p.VG2) {
+            u64* dst = out + offV + (long)j * p.VG2 + p.VG2 - 1;
+            if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
+        }
+        DP_MARK(8)
+        __syncthreads();                                                // H3: dq partials and dconv tiles of all workgroups
+        DP_MARK(9)
+        // ---- P5: dq (sum over tiles), its part of dh_{t-1}, datt_next of the tile
+        {
+            const int QG2f = 2 * p.QG2;
+            float dqv = 0.f;
+            if (aok) for (int i = 0; i < NT; ++i) dqv += s_qst[i * QG2f + a];
+            if (aok) s_dq[a] = dqv;
+            const int asl = (A + NT - 1) / NT;
+            if (aok && a >= j * asl && a < (j + 1) * asl) p.dq[row * A + a] = dqv;     // each workgroup saves a slice
+        }
+        if (t > 0) {
+            // datt_next[tau'] = sum_k sum_j W_conv[k][j] * dconv[k][tau' - j + Ks] for the tile's frames:
+            // item = (tap range, kernel, group of 4 outputs) with a sliding register window; partial sums meet in LDS
+            constexpr int ngrp = TE / 4;
+            const int nitem = Kn * ngrp;
+            const int parts = max(1, min(4, nct / nitem));
+            const int tp = (taps + parts - 1) / parts;
+            for (int it = tid; it < parts * nitem; it += nct) {
+                const int pz = it / nitem, o = it - pz * nitem, k = o / ngrp, ig = o - k * ngrp;
+                const int j0 = pz * tp, j1 = min(taps, j0 + tp);
+                const float* wk = s_wc + k * taps;
+                const float* dc = s_dcp + k * DW + tau0 + 4 * ig + 2 * Ks;      // dc[i - jj] for output i of the group
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                float p1 = 0.f, p2 = 0.f, p3 = 0.f;
+                if (j0 < j1) { p1 = dc[1 - j0]; p2 = dc[2 - j0]; p3 = dc[3 - j0]; }
+                for (int jj = j0; jj < j1; ++jj) {
+                    const float wv = wk[jj], p0 = dc[-jj];
+                    a0 += wv * p0; a1 += wv * p1; a2 += wv * p2; a3 += wv * p3;
+                    p3 = p2; p2 = p1; p1 = p0;
+                }
+                float* o4 = s_pt + (long)(pz * Kn + k) * TE + 4 * ig;
+                o4[0] = a0; o4[1] = a1; o4[2] = a2; o4[3] = a3;
+            }
+        }
+        cbar(&s_bar, gen, ncw);
+        if (t > 0) {
+            // dh_{t-1}[unit] += sum_a dq[a] * W_q[a][unit]: wave w takes units w, w+ncw, ..; lanes over a
+            for (int ul = wave; ul < p.UPW; ul += ncw) {
+                const int unit = min(u_base + ul, Dd - 1);
+                float wq[5];
+#pragma unroll
+                for (int k5 = 0; k5 < 5; ++k5) wq[k5] = p.wqT[(long)unit * A + min(lane + 64 * k5, A - 1)];
+                float acc = 0.f;
+#pragma unroll
+                for (int k5 = 0; k5 < 5; ++k5) if (lane + 64 * k5 < A) acc += s_dq[lane + 64 * k5] * wq[k5];
+                acc = wave_sum(acc);
+                if (lane == 0) s_dhn[ul] += acc;
+            }
+            {
+                const int nitem = Kn * (TE / 4);
+                const int parts = max(1, min(4, nct / nitem));
+                float v = 0.f;
+                if (tid < TE) for (int r = 0; r < parts * Kn; ++r) v += s_pt[(long)r * TE + tid];
+                const float nb = __shfl_down(v, 1);
+                if (tid < TE && (tid & 1) == 0) {
+                    u64* dst = out + offN + (long)j * p.NG2 + (tid >> 1);
+                    if (local) publish<true>(dst, pack2(v, (tid + 1 < TE) ? nb : 0.f, want)); else publish<false>(dst, pack2(v, (tid + 1 < TE) ? nb : 0.f, want));
+                }
+                if (tid == 0 && TE / 2 < p.NG2) {
+                    u64* dst = out + offN + (long)j * p.NG2 + p.NG2 - 1;
+                    if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
+                }
+            }
+        }
+        DP_MARK(10)
+        __syncthreads();                                                // H4: s_dn holds datt_next for the next step
+        DP_MARK(11)
+    }
+    DP_DUMP
+    // ---- results that were accumulated on chip: dkey tile and the slot of this workgroup
+    if (aok) {
+        float* sl = p.slots + ((long)b * NT + j) * p.slot;
+        sl[a] = dwg;
+#pragma unroll
+        for (int k = 0; k < KNMAX; ++k) if (k < Kn) sl[A + k * A + a] = dwp[k];
+    }
+    if (tid == 0) p.slots[((long)b * NT + j) * p.slot + A * (1 + Kn)] = dbg;
+}
+
+struct PersistPlanB { bool ok; int TE, NT, UPW, CPW, R4, GG2, CG2, QG2, VG2, NG2; size_t lds, status_bytes, xbuf_bytes, w16_bytes, total; };
+
+PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
+    PersistPlanB pl{};
+    pl.ok = false;
+    if (d.NL != 1 || d.B > 64 || d.A > 320 || d.Kn > 10 || (d.E & 7) != 0 || d.E > 640 || (d.A & 1) != 0) return pl;
+    const int cpx = cdiv(d.B, 8);
+    int TE = 0;
+    const int cand[] = {16, 40};
+    for (int i = 0; i < 2; ++i) { const int nt = cdiv(d.Tp, cand[i]); if (nt <= 30 && cpx * nt <= 32) { TE = cand[i]; break; } }
+    if (!TE) return pl;
+    pl.TE = TE; pl.NT = cdiv(d.Tp, TE);
+    pl.UPW = cdiv(d.Dd, pl.NT); pl.CPW = cdiv(d.E, pl.NT);
+    const int ncw = cdiv(d.A, 64);
+    if (pl.UPW > 64 || pl.UPW + pl.CPW > NOUTW * ncw || ncw > 5 || 8 * TE > 64 * ncw) return pl;   // P2 maps 8 threads to a frame
+    pl.R4 = (4 * d.Dd + 7) & ~7;
+    auto even = [](int x) { return (x + 1) & ~1; };
+    pl.GG2 = even(4 * (even(pl.UPW) / 2)); pl.CG2 = even(even(pl.CPW) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even(TE / 2);
+    const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.R4, pl.GG2, pl.CG2, pl.QG2, pl.NG2);
+    pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
+    if (pl.lds > 150 * 1024) return pl;
+    pl.status_bytes = 4096;
+    pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.GG2 + pl.CG2 + pl.QG2 + pl.VG2 + pl.NG2) * sizeof(u64));
+    pl.w16_bytes = align_up256((size_t)(d.Dd + d.E + d.Dd) * pl.R4 * 2);
+    pl.total = pl.status_bytes + pl.xbuf_bytes + pl.w16_bytes;
+    pl.ok = true;
+    return pl;
+}
+
+__global__ void cast_rows_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int rows, int cols, int ldd) {
+    const long total = (long)rows * ldd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ldd), c = (int)(i - (long)r * ldd);
+        dst[i] = (c < cols) ? f2bf_bits(src[(long)r * cols + c]) : (unsigned short)0;
+    }
+}
+
+}  // namespace
+
+size_t dec_bwd_persist_work_bytes(const asr_dec_dims_t& d) { const PersistPlanB pl = persist_plan_b(d); return pl.ok ? pl.total : 0; }
+int dec_bwd_persist_tiles(const asr_dec_dims_t& d) { const PersistPlanB pl = persist_plan_b(d); return pl.ok ? pl.NT : 0; }
+
+// Returns ASR_OK when the whole backward loop was launched, 1 when there is no persistent plan, negative on error.
+// dhs: (B,L,Dd) gradient wrt h from the output layer; wcatT: ((Dd+E+Dd) x 4Dd) fp32 transposed [W_ih | W_hh]; wqT: (Dd x A).
+int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const int64_t* enc_len,
+                       const float* dhs, float* dxin, float* dq, float* dkey, float* slots, int slot, const float* wcatT, const float* wqT,
+                       void* work, size_t work_bytes, hipStream_t st) {
+    if (g_persist_bwd < 0) { const char* e = getenv("ASR_DEC_PERSIST_BWD"); g_persist_bwd = (e && e[0] == '0') ? 0 : 1; }
+    const PersistPlanB pl = persist_plan_b(d);
+    if (!g_persist_bwd || !pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv || !s.enc16) return 1;
+    char* base = (char*)work;
+    unsigned* status = (unsigned*)base;
+    u64* xbuf = (u64*)(base + pl.status_bytes);
+    unsigned short* w16 = (unsigned short*)(base + pl.status_bytes + pl.xbuf_bytes);
+    hipMemsetAsync(work, 0, pl.status_bytes + pl.xbuf_bytes, st);
+    hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3(512), dim3(256), 0, st, wcatT, w16, d.Dd + d.E + d.Dd, 4 * d.Dd, pl.R4);
+    static unsigned epoch_counter = 7;
+    static int allow = -1;
+    if (allow < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); allow = (e && e[0] == '0') ? 0 : 1; }
+    PB p{d, w, s, (const unsigned short*)s.enc16, enc_len, dhs, dxin, dq, dkey, slots, w16, wqT, xbuf, status,
+         slot, pl.NT, pl.UPW, pl.CPW, pl.R4, pl.GG2, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, epoch_counter++};
+    const int cpx = cdiv(d.B, 8), ncw = cdiv(d.A, 64);
+    const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
+#define DPB_LAUNCH(KN_, TE_)                                                                                                    \
+    {                                                                                                                           \
+        static bool attr = false;                                                                                               \
+        if (!attr) { hipFuncSetAttribute((const void*)dec_bwd_persist<KN_, TE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr = true; } \
+        hipLaunchKernelGGL((dec_bwd_persist<KN_, TE_>), grid, block, pl.lds, st, p);                                              \
+    }
+    if (d.Kn <= 4) { if (pl.TE == 16) DPB_LAUNCH(4, 16) else DPB_LAUNCH(4, 40) }
+    else { if (pl.TE == 16) DPB_LAUNCH(10, 16) else DPB_LAUNCH(10, 40) }
+#undef DPB_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { asr_set_error("asr_att_decoder_bwd(persistent): launch failed: %s", hipGetErrorString(e)); return ASR_E_LAUNCH; }
     return ASR_OK;
 }

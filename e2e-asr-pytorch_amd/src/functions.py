@@ -331,6 +331,7 @@ class AttDecoderFn(torch.autograd.Function):
         s = H.dec_state_struct(st)
         nbytes = H.lib().asr_att_decoder_bwd_workspace_bytes(ctypes.byref(d))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+        model._last_dec_bwd_ws = ws          # kept for diagnostics (tools/diag_dec.py)
         H.call('asr_att_decoder_bwd', ctypes.byref(d), ctypes.byref(w), ctypes.byref(g), H.ptr(enc), H.ptr(enc_len),
                ctypes.byref(s), H.ptr(dlogits), H.ptr(denc), H.ptr(ws), nbytes, prec, H.stream_ptr())
         ctx.st = None

@@ -86,6 +86,8 @@ _RESTYPES = {
     'asr_fbank_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'asr_att_decoder_bwd_workspace_bytes': (_sz, [_P(DecDims)]),
     'asr_att_decoder_fwd_work_bytes': (_sz, [_P(DecDims)]),
+    'asr_att_decoder_set_persistent': (ctypes.c_int, [_i]),
+    'asr_att_decoder_bwd_status_offset': (_sz, [_P(DecDims)]),
 }
 
 

@@ -197,6 +197,9 @@ int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* wei
                         const float* enc, const int64_t* enc_len, const int64_t* teacher, int teacher_ld,
                         const asr_dec_state_t* state, int prec, asr_stream_t stream);
 size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims);
+/* bit 0 / bit 1: run the teacher-forced forward / backward loop as one persistent launch where the shape has a plan
+ * (default on, env ASR_DEC_PERSIST / ASR_DEC_PERSIST_BWD); returns the previous flags.  For A/B tests. */
+int asr_att_decoder_set_persistent(int flags);
 /* bytes of state->work that let asr_att_decoder_fwd run the teacher-forced loop as ONE persistent launch (0: shape has no plan) */
 size_t asr_att_decoder_fwd_work_bytes(const asr_dec_dims_t* dims);
 /* dlogits (B,L,V) in; denc (B,Tp,E) accumulated (+=); parameter gradients accumulated into `grads`.

@@ -59,3 +59,44 @@ def test_persistent_forward_matches_step_kernels(B, Tp, L):
         n = int(enc_len[bi])
         err = (st_p['conv'][bi, :, :, :n] - st_s['conv'][bi, :, :, :n]).abs().max().item()
         assert err < 2e-3, 'conv row %d differs by %g' % (bi, err)
+
+
+@pytest.mark.parametrize('B,Tp,L', [(16, 600, 10), (3, 170, 9), (9, 333, 7), (4, 18, 5)])
+def test_persistent_backward_matches_step_kernels(B, Tp, L):
+    """Gradients of the decoder (all parameters + encoder output) with the loop as one persistent launch vs the per-step
+    kernels, from the same forward state."""
+    from src import hipabi as H
+    from src import functions as F
+    model = _model('librispeech_asr.yaml')
+    g = torch.Generator().manual_seed(7 * B + Tp)
+    E = 640
+    enc0 = torch.tanh(torch.randn(B, Tp, E, generator=g)).cuda()
+    enc_len = torch.randint(max(Tp // 3, 1), Tp + 1, (B,), generator=g)
+    enc_len[0] = Tp
+    enc_len = enc_len.cuda()
+    teacher = torch.randint(2, 31, (B, L), generator=g).cuda()
+    dlog = (torch.randn(B, L, 31, generator=g) * 0.1).cuda()
+    names = [n for n, _ in model.named_parameters() if n.startswith(('decoder', 'attention', 'pre_embed'))]
+    out = {}
+    old = H.lib().asr_att_decoder_set_persistent(3)
+    try:
+        for mode in (3, 1):
+            H.lib().asr_att_decoder_set_persistent(mode)
+            model.zero_grad()
+            enc = enc0.clone().requires_grad_(True)
+            logits, _, _ = F.AttDecoderFn.apply(model._anchor, enc, enc_len, teacher, L, model, H.BF16)
+            (logits * dlog).sum().backward()
+            torch.cuda.synchronize()
+            out[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if n in names}
+            out[mode]['enc'] = enc.grad.detach().clone()
+    finally:
+        H.lib().asr_att_decoder_set_persistent(old)
+    for n in out[3]:
+        a, b_ = out[3][n].double(), out[1][n].double()
+        assert torch.isfinite(a).all(), n
+        if n.endswith('gen_energy.bias'):
+            # analytically zero (softmax is shift invariant): both values are rounding noise
+            assert float(a.abs().max()) < 1e-3 and float(b_.abs().max()) < 1e-3
+            continue
+        rel = float((a - b_).norm() / (b_.norm() + 1e-12))
+        assert rel < 2e-2, '%s: relative difference %g' % (n, rel)

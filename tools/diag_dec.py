@@ -40,3 +40,29 @@ for it in range(2):
         tot += us
         print('   %-32s %7.2f us/step' % (nm, us))
     print('   %-32s %7.2f us/step' % ('sum', tot))
+
+# ---- backward
+from src import functions as F2
+NB = ['wait H4 .. P0 start', 'P0 cell bwd + publish G', 'wait G (H1)', 'scatter + barrier', 'P1 transposed weights . dgates', 'C publish, conv tile load, wait C (H2)',
+      'P2 dattn + dot + de', 'P3 sweep + Q publish', 'P4 dconv + V publish', 'wait Q,V (H3)', 'P5 dq, query part, datt_next, N publish', 'wait N (H4)']
+model.zero_grad()
+enc2 = enc.clone().requires_grad_(True)
+logits, _, _ = F2.AttDecoderFn.apply(model._anchor, enc2, enc_len, teacher, L, model, H.BF16)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+gout = torch.randn_like(logits) * 0.1
+torch.cuda.synchronize()
+e0.record()
+logits.backward(gout)
+e1.record(); torch.cuda.synchronize()
+print('decoder backward: %.2f ms' % e0.elapsed_time(e1))
+d = F2._dec_dims(model, B, Tp, L)
+off = int(H.lib().asr_att_decoder_bwd_status_offset(ctypes.byref(d)))
+w = model._last_dec_bwd_ws[off:off + 4096].view(torch.int64).cpu().tolist()
+print('abort=%d modes %s' % (w[0] & 0xffffffff, w[26:34]))
+ticks = w[128:144]
+tot = 0.0
+for k, nm in enumerate(NB):
+    us = ticks[k] * 0.01 / L
+    tot += us
+    print('   %-48s %7.2f us/step' % (nm, us))
+print('   %-48s %7.2f us/step' % ('sum', tot))

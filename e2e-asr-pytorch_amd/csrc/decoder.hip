@@ -1129,7 +1129,7 @@ namespace { size_t dec_bwd_persist_work_bytes_fw(const asr_dec_dims_t& d) { retu
             int dec_bwd_persist_tiles_fw(const asr_dec_dims_t& d) { return dec_bwd_persist_tiles(d); } }
 int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const int64_t* enc_len,
                        const float* dhs, float* dxin, float* dq, float* dkey, float* slots, int slot, const float* wcatT, const float* wqT,
-                       void* work, size_t work_bytes, hipStream_t st);
+                       void* work, size_t work_bytes, float** dgates_out, hipStream_t st);
 
 extern "C" size_t asr_att_decoder_fwd_work_bytes(const asr_dec_dims_t* dims) {
     return dims ? dec_fwd_persist_work_bytes(*dims) : 0;
@@ -1332,16 +1332,17 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     }
     int nslots_used = d.B * lay.nte;
     bool looped = false;
+    float* pdg = nullptr;         // gate gradients of the persistent backward (it leaves the saved gates intact)
     if (bf && lay.ntp > 0 && state->enc16 && d.NL == 1) {
         // the whole loop as one persistent, cluster-per-utterance launch (decoder_persist.hip)
         rc = dec_bwd_persistent(d, *weights, *state, enc_len, p.dhs, p.dxin, p.dq, p.dkey, p.slots, lay.slot, p.wcatT[0], p.wqT,
-                                ws + lay.pwork, lay.pwork_bytes, st);
+                                ws + lay.pwork, lay.pwork_bytes, &pdg, st);
         if (rc < 0) return rc;
         if (rc == ASR_OK) {
             looped = true;
             nslots_used = d.B * lay.ntp;
             // embedding part of dxin: dgates (B*L x 4Dd) . W_ih[:, :Dd]   (the context part was written by the kernel)
-            rc = asr_gemm(state->gates, weights->Wih[0], p.dxin, nullptr, BL, d.Dd, 4 * d.Dd, 4 * d.Dd, XW, XW, 1, 0, ASR_ACT_NONE, 0, 1, 1,
+            rc = asr_gemm(pdg, weights->Wih[0], p.dxin, nullptr, BL, d.Dd, 4 * d.Dd, 4 * d.Dd, XW, XW, 1, 0, ASR_ACT_NONE, 0, 1, 1,
                           0, 0, 0, 0, 0, prec, stream);
             if (rc != ASR_OK) return rc;
         }
@@ -1379,7 +1380,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
 
     // ---- batched parameter gradients -----------------------------------------------------------
     for (int l = 0; l < d.NL; ++l) {
-        const float* dg = state->gates + (size_t)l * 4 * d.Dd;   // rows (b,t), stride NL*4Dd
+        const float* dg = looped ? pdg : state->gates + (size_t)l * 4 * d.Dd;   // rows (b,t), stride NL*4Dd
         const long ldg = (long)d.NL * 4 * d.Dd;
         const int Kx = (l == 0) ? XW : d.Dd;
         const float* xl = (l == 0) ? state->xin : state->hs + (size_t)(l - 1) * d.Dd;

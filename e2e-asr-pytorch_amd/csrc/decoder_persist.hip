@@ -591,21 +591,30 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
 
 // =================================================================================================
 // Backward of the teacher-forced decoder loop as ONE persistent launch (same cluster-per-utterance scheme as the
-// forward; bf16 mode, one decoder layer).  Resident per workgroup (tile j of utterance b) for all L steps: the key tile
-// (bf16, LDS), W_proj / W_conv, and IN REGISTERS the accumulators that the per-step kernels had to read-modify-write in
-// HBM every step: d w_g[a], d W_proj[a,:], the cell-state carry; the dkey tile is still read-modify-written, but in the L2 of
-// the XCD that owns the cluster (the same workgroup touches the same 48 KB every step).
-// Per step five all-gathers inside the cluster (tagged granules):
-//   G  gate-gradient rows of the workgroup's hidden units          -> every workgroup has dgates[4Dd]
-//   C  dctx slice (workgroup j owns CPW context columns)            -> every workgroup has dctx[E]
-//   Q  per-tile partial of the query gradient, V the tile's dconv   -> dq[A] (sum over tiles), dconv[Kn, T']
-//   N  the tile's gradient wrt the previous attention               -> datt_next[T'] for the next step
-// Waves 0..ncw-1 (ncw = ceil(A/64)) compute, three more waves only poll.
+// forward; bf16 mode, one decoder layer).  Workgroup (tile j of utterance b) keeps for all L steps
+//   * in REGISTERS: its rows of [W_ih(ctx) | W_hh]^T (bf16, 8 rows x 20 columns per lane over all 8 waves), its rows of
+//     W_q^T, and the accumulators the per-step kernels had to read-modify-write in HBM every step: d w_g[a], d W_proj[a,:],
+//     the cell-state carry;
+//   * in LDS: the key tile (bf16), W_proj (bf16, MFMA operand), W_conv;
+//   * dkey is accumulated with no-return atomics (one add per address per step, issued by the same thread: deterministic).
+// Every workgroup recomputes the (elementwise) cell backward of ALL hidden units from the full dh vector, so a step
+// needs three all-gathers inside the cluster (tagged granules):
+//   C  {dctx slice, recurrent part of dh_{t-1} for the workgroup's units}
+//   Q  per-tile partial of the query gradient,  V  the tile's dconv
+//   N  {the tile's gradient wrt the previous attention, query part of dh_{t-1} for the workgroup's units}
+// Waves 0..ncw-1 (ncw = ceil(A/64)) compute, three more waves poll; all eight take part in the transposed-weight product.
 // =================================================================================================
 namespace {
 
 constexpr int NPB = 3;            // polling waves of the backward kernel
-constexpr int NOUTW = 13;         // dctx / dh outputs per compute wave in the transposed-weight product
+constexpr int RPWB = 8;           // rows of the transposed-weight product per wave
+constexpr int KCHB = 5;           // 4-column chunks of the gate-gradient vector per lane (4*Dd <= 1280)
+constexpr int UQW = 4;            // hidden units per compute wave in the query-part product
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+__device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_, a), __builtin_bit_cast(bf16x2_, b), c, false);
+}
 
 struct PB {
     asr_dec_dims_t d;
@@ -616,43 +625,46 @@ struct PB {
     const float* dhs;               // (B,L,Dd) gradient wrt h_t from the output layer
     float* dxin;                    // (B,L,Dd+E)  context part written here
     float* dq;                      // (B,L,A)     gradient wrt the query pre-activation
-    float* dkey;                    // (B,T',A)
+    float* dkey;                    // (B,T',A)    zero on entry, accumulated atomically
     float* slots;                   // (B*NT, slot)  d w_g [a], d W_proj [k][a], d b_g
+    float* dgates;                  // (B,L,4Dd)   gate pre-activation gradients (the saved gates stay intact)
     const unsigned short* wcatT16;  // (Dd+E+Dd rows = input columns) x R4 bf16, row x = gradient weights of input column x
     const float* wqT;               // (Dd x A)
     u64* xbuf;
     unsigned* status;
     int slot, NT, UPW, CPW, R4;
-    int GG2, CG2, QG2, VG2, NG2;    // granules per producer record (even)
+    int CG2, QG2, VG2, NG2;         // granules per producer record (even)
     int allow_local;
     unsigned epoch;
+    int poll_delay;                 // s_sleep units before the Q/V polling starts
 };
 
-// LDS carve of dec_bwd_persist, shared by the kernel and the host plan (offsets in floats after the two bf16 tiles).
-struct BCarve { int AP, DW, shorts; int wpT, wc, dg, dctx, qst, dn, dcp, cv, de, out, dhn, pt, dcx, dq, gst, floats; };
-__host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn, int Ks, int NT, int UPW, int R4,
-                                            int GG2, int CG2, int QG2, int NG2) {
+// LDS carve of dec_bwd_persist, shared by the kernel and the host plan (float offsets follow the bf16 arrays).
+struct BCarve { int AP, DW, key, dl, wp16, dg16, shorts; int wc, crec, qst, nrec, dcp, cv, de, out, hq, pt, dcx, dq, floats; };
+__host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn, int Ks, int NT, int UPW, int CG2, int QG2, int NG2) {
     BCarve c;
-    int ap8 = (A + 7) >> 3; if ((ap8 & 1) == 0) ++ap8;
-    c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: 16-byte rows, odd in 16-byte units
+    int ap8 = 4 * ((A + 31) / 32); if ((ap8 & 1) == 0) ++ap8;
+    c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: >= 32*ceil(A/32), odd in 16-byte units
     c.DW = (NT * TE + 2 * Ks + 8 + 3) & ~3;             // zero-padded dconv row
-    c.shorts = ((TE * A + 7) & ~7) + TE * c.AP;
     int o = 0;
-    c.wpT = o; o += Kn * c.AP;
+    c.key = o; o += (TE * A + 7) & ~7;
+    c.dl = o; o += TE * c.AP;
+    c.wp16 = o; o += 16 * c.AP;
+    c.dg16 = o; o += 64 * KCHB * 4;
+    c.shorts = o;
+    o = 0;
     c.wc = o; o += (Kn * (2 * Ks + 1) + 3) & ~3;
-    c.dg = o; o += R4;
-    c.dctx = o; o += NT * CG2 * 2;
+    c.crec = o; o += NT * CG2 * 2;
     c.qst = o; o += NT * QG2 * 2;
-    c.dn = o; o += NT * NG2 * 2 + 8;
+    c.nrec = o; o += NT * NG2 * 2 + 8;
     c.dcp = o; o += Kn * c.DW;
     c.cv = o; o += TE * KP;
     c.de = o; o += (TE + 3) & ~3;
-    c.out = o; o += NOUTW * 8;
-    c.dhn = o; o += (UPW + 3) & ~3;
+    c.out = o; o += RPWB * 8;
+    c.hq = o; o += 64;
     c.pt = o; o += 4 * Kn * TE;
     c.dcx = o; o += (E + 3) & ~3;
     c.dq = o; o += (A + 3) & ~3;
-    c.gst = o; o += NT * GG2 * 2;
     c.floats = o;
     return c;
 }
@@ -682,12 +694,31 @@ __device__ __forceinline__ void poll_copy(const u64* src, int n16, float* dst, i
     }
 }
 
+// rows of [W_ih(ctx) | W_hh]^T (registers) . dgates (bf16, LDS): output oo = wave + nw*o -> s_out[oo]
+#define DPB_P1()                                                                                                       \
+    {                                                                                                                  \
+        float acc_[RPWB];                                                                                              \
+        _Pragma("unroll") for (int o = 0; o < RPWB; ++o) acc_[o] = 0.f;                                                \
+        _Pragma("unroll") for (int k = 0; k < KCHB; ++k) {                                                             \
+            const uint2 g_ = *reinterpret_cast<const uint2*>(s_dg16 + 4 * (lane + 64 * k));                            \
+            _Pragma("unroll") for (int o = 0; o < RPWB; ++o) {                                                         \
+                acc_[o] = dot2bf(wreg[o][k].x, g_.x, acc_[o]);                                                         \
+                acc_[o] = dot2bf(wreg[o][k].y, g_.y, acc_[o]);                                                         \
+            }                                                                                                          \
+        }                                                                                                              \
+        _Pragma("unroll") for (int o = 0; o < RPWB; ++o) {                                                             \
+            const float sv_ = wave_sum(acc_[o]);                                                                       \
+            if (lane == 0 && wave + nw * o < nout) s_out[wave + nw * o] = sv_;                                         \
+        }                                                                                                              \
+    }
+
 template <int KNMAX, int TE>
 __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_bar;
     __shared__ float s_red[8];
     constexpr int KP = (KNMAX + 3) & ~3;
+    constexpr int MT = (TE + 15) / 16;
     const asr_dec_dims_t& d = p.d;
     const int id = blockIdx.x, xcd = id & 7, slot_id = id >> 3;
     const int cb = slot_id / p.NT, j = slot_id - cb * p.NT;
@@ -695,41 +726,41 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     if (b >= d.B) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = p.NT, A = d.A, E = d.E, Dd = d.Dd, Tp = d.Tp, Kn = d.Kn, Ks = d.Ks, L = d.L;
-    const int ncw = (A + 63) >> 6, nct = 64 * ncw;                     // compute waves / threads
+    const int ncw = (A + 63) >> 6, nct = 64 * ncw, nw = ncw + NPB;       // compute waves / threads, all waves
     const int taps = 2 * Ks + 1, XW = Dd + E, R4 = p.R4;
     const int tau0 = j * TE;
     const int len = min((int)p.enc_len[b], Tp);
     const int tmax = max(len - 1, 0);
-    const BCarve cv_ = bwd_carve(TE, KP, A, E, Kn, Ks, NT, p.UPW, R4, p.GG2, p.CG2, p.QG2, p.NG2);
+    const BCarve cv_ = bwd_carve(TE, KP, A, E, Kn, Ks, NT, p.UPW, p.CG2, p.QG2, p.NG2);
     const int AP = cv_.AP, DW = cv_.DW;
     const int TW = NT * TE;                                             // padded attention row
+    const int CG2f = 2 * p.CG2, NG2f = 2 * p.NG2, QG2f = 2 * p.QG2;
     // ---- LDS carve
-    unsigned short* s_key = reinterpret_cast<unsigned short*>(smem);                    // [TE][A] bf16
-    unsigned short* s_dl = s_key + ((TE * A + 7) & ~7);                                  // [TE][AP] bf16  d loc pre-activation
-    float* s_f = reinterpret_cast<float*>(s_key + cv_.shorts);
-    float* s_wpT = s_f + cv_.wpT;                                                        // [Kn][AP]
+    unsigned short* s_sh = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* s_key = s_sh + cv_.key;                                              // [TE][A] bf16
+    unsigned short* s_dl = s_sh + cv_.dl;                                                // [TE][AP] bf16  d loc pre-activation
+    unsigned short* s_wp16 = s_sh + cv_.wp16;                                            // [16][AP] bf16  W_proj^T, zero padded
+    unsigned short* s_dg16 = s_sh + cv_.dg16;                                            // [1280] bf16 dgates of the utterance
+    float* s_f = reinterpret_cast<float*>(s_sh + cv_.shorts);
     float* s_wc = s_f + cv_.wc;                                                          // [Kn*taps]
-    float* s_dg = s_f + cv_.dg;                                                          // [R4]    dgates of the utterance
-    float* s_dctx = s_f + cv_.dctx;                                                      // [NT*CG2*2] gathered dctx slices (flat records)
+    float* s_crec = s_f + cv_.crec;                                                      // [NT][CG2*2] records {dctx slice, dh_rec slice}
     float* s_qst = s_f + cv_.qst;                                                        // [NT][QG2*2] dq partials
-    float* s_dn = s_f + cv_.dn;                                                          // [NT*NG2*2 + pad] datt_next (flat records = frames)
-    float* s_dcp = s_f + cv_.dcp;                                                        // [Kn][DW] zero-padded dconv rows (Ks + TW + Ks + pad)
+    float* s_nrec = s_f + cv_.nrec;                                                      // [NT][NG2*2] records {datt_next tile, dh_q slice}
+    float* s_dcp = s_f + cv_.dcp;                                                        // [Kn][DW] zero-padded dconv rows
     float* s_cv = s_f + cv_.cv;                                                          // [TE][KP]
     float* s_de = s_f + cv_.de;                                                          // [TE]
-    float* s_out = s_f + cv_.out;                                                        // [NOUTW * 8] products of P1, then scratch
-    float* s_dhn = s_f + cv_.dhn;                                                        // [UPW] dh carried to step t-1
+    float* s_out = s_f + cv_.out;                                                        // [RPWB * 8] products of P1
+    float* s_hq = s_f + cv_.hq;                                                          // [UPW] query part of dh_{t-1}
     float* s_pt = s_f + cv_.pt;                                                          // [4*Kn*TE] partial sums of datt_next (tap ranges)
     float* s_dcx = s_f + cv_.dcx;                                                        // [E] dctx, contiguous
     float* s_dq = s_f + cv_.dq;                                                          // [A] dq of the utterance
-    float* s_gst = s_f + cv_.gst;                                                        // [NT][GG2*2] gathered gate-gradient records
-    const long region = (long)NT * (p.GG2 + p.CG2 + p.QG2 + p.VG2 + p.NG2);
+    const long region = (long)NT * (p.CG2 + p.QG2 + p.VG2 + p.NG2);
     auto xb = [&](int parity) { return p.xbuf + ((long)parity * d.B + b) * region; };
-    const long offC = (long)NT * p.GG2, offQ = offC + (long)NT * p.CG2, offV = offQ + (long)NT * p.QG2, offN = offV + (long)NT * p.VG2;
+    const long offC = 0, offQ = offC + (long)NT * p.CG2, offV = offQ + (long)NT * p.QG2, offN = offV + (long)NT * p.VG2;
     if (tid == 0) s_bar = 0u;
     // clear this producer's records in the L2 (see the forward kernel)
     for (int parity = 0; parity < 2; ++parity) {
         u64* base = xb(parity);
-        for (int i = tid; i < p.GG2; i += blockDim.x) st_gran_local(base + (long)j * p.GG2 + i, 0ull);
         for (int i = tid; i < p.CG2; i += blockDim.x) st_gran_local(base + offC + (long)j * p.CG2 + i, 0ull);
         for (int i = tid; i < p.QG2; i += blockDim.x) st_gran_local(base + offQ + (long)j * p.QG2 + i, 0ull);
         for (int i = tid; i < p.VG2; i += blockDim.x) st_gran_local(base + offV + (long)j * p.VG2 + i, 0ull);
@@ -744,13 +775,30 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         const int f = i / A, a = i - f * A;
         s_key[i] = f2bf_bits(p.s.key[((long)b * Tp + min(tau0 + f, tmax)) * A + a]);
     }
-    for (int i = tid; i < Kn * AP; i += blockDim.x) { const int k = i / AP, a = i - k * AP; s_wpT[i] = (a < A) ? p.w.Wproj[a * Kn + k] : 0.f; }
+    for (int i = tid; i < 16 * AP; i += blockDim.x) { const int k = i / AP, a = i - k * AP; s_wp16[i] = (k < Kn && a < A) ? f2bf_bits(p.w.Wproj[a * Kn + k]) : (unsigned short)0; }
     for (int i = tid; i < Kn * taps; i += blockDim.x) s_wc[i] = p.w.Wconv[i];
-    for (int i = tid; i < R4; i += blockDim.x) s_dg[i] = 0.f;
-    for (int i = tid; i < NT * p.NG2 * 2 + 8; i += blockDim.x) s_dn[i] = 0.f;
+    for (int i = tid; i < 64 * KCHB * 4; i += blockDim.x) s_dg16[i] = 0;
+    for (int i = tid; i < NT * NG2f + 8; i += blockDim.x) s_nrec[i] = 0.f;
+    for (int i = tid; i < NT * CG2f; i += blockDim.x) s_crec[i] = 0.f;
     for (int i = tid; i < Kn * DW; i += blockDim.x) s_dcp[i] = 0.f;
     for (int i = tid; i < TE * AP; i += blockDim.x) s_dl[i] = 0;
-    for (int i = tid; i < p.UPW; i += blockDim.x) s_dhn[i] = 0.f;
+    for (int i = tid; i < TE * KP; i += blockDim.x) s_cv[i] = 0.f;
+    // register-resident rows of the transposed cell weights: output oo = wave + nw*o, columns 4*(lane + 64k) .. +3
+    const int u_base = j * p.UPW, c_base = j * p.CPW;
+    const int nout = p.CPW + p.UPW;
+    uint2 wreg[RPWB][KCHB];
+#pragma unroll
+    for (int o = 0; o < RPWB; ++o) {
+        const int oo = wave + nw * o;
+        int x = (oo < p.CPW) ? Dd + min(c_base + oo, E - 1) : XW + min(u_base + (oo - p.CPW), Dd - 1);
+        if (oo >= nout) x = Dd;
+#pragma unroll
+        for (int k = 0; k < KCHB; ++k) {
+            const int col = 4 * (lane + 64 * k);
+            const uint2 v = *reinterpret_cast<const uint2*>(p.wcatT16 + (long)x * R4 + min(col, R4 - 4));
+            wreg[o][k] = (col < R4) ? v : make_uint2(0u, 0u);
+        }
+    }
     __syncthreads();
 
     if (wave >= ncw) {
@@ -760,10 +808,12 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             const int s = L - 1 - t;                                     // step counter of this launch (tags, parity)
             const u64 want = pair_want(seq_of(s), p.epoch);
             const u64* base = xb(s & 1);
-            poll_copy<4>(base, NT * p.GG2 / 2, s_gst, gt, np, want, p.status);
-            __syncthreads();                                            // H1
-            poll_copy<4>(base + offC, NT * p.CG2 / 2, s_dctx, gt, np, want, p.status);
+            __syncthreads();                                            // Ba: s_dg16 holds the gate gradients of step t
+            DPB_P1()
+            __syncthreads();                                            // Bb: s_out complete
+            poll_copy<4>(base + offC, NT * p.CG2 / 2, s_crec, gt, np, want, p.status);
             __syncthreads();                                            // H2
+            for (int z = 0; z < p.poll_delay; ++z) __builtin_amdgcn_s_sleep(127);
             poll_copy<8>(base + offQ, NT * p.QG2 / 2, s_qst, gt, np, want, p.status);
             {   // dconv tiles go straight into the zero-padded per-kernel rows: s_dcp[k][Ks + prod*TE + f]
                 const int n16 = NT * p.VG2 / 2;
@@ -787,7 +837,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                 }
             }
             __syncthreads();                                            // H3
-            if (t > 0) poll_copy<4>(base + offN, NT * p.NG2 / 2, s_dn, gt, np, want, p.status);
+            if (t > 0) poll_copy<4>(base + offN, NT * p.NG2 / 2, s_nrec, gt, np, want, p.status);
             __syncthreads();                                            // H4
         }
         return;
@@ -795,16 +845,35 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
 
     // =========================== compute role ===========================
     unsigned gen = 0;
-    const int u_base = j * p.UPW, c_base = j * p.CPW;
     const int a = tid;                                                  // attention column of this thread in the sweep
     const bool aok = a < A;
     const int ac = aok ? a : A - 1;
+    const bool uok = tid < Dd;                                          // hidden unit of this thread in the cell backward
+    const int uc = uok ? tid : Dd - 1;
+    const int ui = uc / p.UPW, uul = uc - ui * p.UPW;                   // its producer and position in the records
+    const bool uown = uok && ui == j;
     float wp[KNMAX], dwp[KNMAX];
 #pragma unroll
     for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < Kn) ? p.w.Wproj[ac * Kn + k] : 0.f; dwp[k] = 0.f; }
     const float wga = p.w.wg[ac];
+    float wq[UQW][5];                                                   // W_q^T rows of units u_base + wave + ncw*i, columns lane + 64k
+#pragma unroll
+    for (int i = 0; i < UQW; ++i) {
+        const int unit = min(u_base + min(wave + ncw * i, p.UPW - 1), Dd - 1);
+#pragma unroll
+        for (int k5 = 0; k5 < 5; ++k5) wq[i][k5] = (lane + 64 * k5 < A) ? p.wqT[(long)unit * A + min(lane + 64 * k5, A - 1)] : 0.f;
+    }
     float dwg = 0.f, dbg = 0.f, dc_carry = 0.f;
-    const int nout = p.CPW + p.UPW;
+    // operands of the cell backward of step L-1 (later steps: requested one step ahead)
+    float pgi, pgf, pgg, pgo, pct, pcp, pdh;
+    {
+        const long r0 = (long)b * L + (L - 1);
+        const float* g = p.s.gates + r0 * 4 * Dd + uc;
+        pgi = g[0]; pgf = g[Dd]; pgg = g[2 * Dd]; pgo = g[3 * Dd];
+        pct = p.s.cs[r0 * Dd + uc];
+        pcp = (L > 1) ? p.s.cs[(r0 - 1) * Dd + uc] : 0.f;
+        pdh = p.dhs[r0 * Dd + uc];
+    }
     DP_DECL
 
     for (int t = L - 1; t >= 0; --t) {
@@ -813,172 +882,119 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         const u64 want = pair_want(seq_of(s), p.epoch);
         u64* out = xb(s & 1);
         DP_MARK(0)
-        // ---- P0: cell backward of the workgroup's hidden units (wave 0), gate-gradient record
-        if (wave == 0) {
-            const int unit = u_base + lane;
-            const bool uok = lane < p.UPW && unit < Dd;
-            float dg4[4] = {0.f, 0.f, 0.f, 0.f};
+        // ---- S1: cell backward of ALL hidden units (thread per unit; every workgroup of the cluster computes the same)
+        {
+            float dh = pdh;
+            if (s > 0) dh += s_crec[ui * CG2f + p.CPW + uul] + s_nrec[ui * NG2f + TE + uul];
+            const float tc = tanhf(pct);
+            const float dc = dh * pgo * (1.f - tc * tc) + dc_carry;
+            const float d0 = dc * pgg * pgi * (1.f - pgi), d1 = dc * pcp * pgf * (1.f - pgf);
+            const float d2 = dc * pgi * (1.f - pgg * pgg), d3 = dh * tc * pgo * (1.f - pgo);
+            dc_carry = dc * pgf;
             if (uok) {
-                float* g = p.s.gates + row * 4 * Dd + unit;
-                const float gi = g[0], gf = g[Dd], gg = g[2 * Dd], go = g[3 * Dd];
-                const float ct = p.s.cs[row * Dd + unit];
-                const float cp = (t > 0) ? p.s.cs[(row - 1) * Dd + unit] : 0.f;
-                const float dh = p.dhs[row * Dd + unit] + s_dhn[lane];
-                const float tc = tanhf(ct);
-                const float dc = dh * go * (1.f - tc * tc) + dc_carry;
-                dg4[0] = dc * gg * gi * (1.f - gi);
-                dg4[1] = dc * cp * gf * (1.f - gf);
-                dg4[2] = dc * gi * (1.f - gg * gg);
-                dg4[3] = dh * tc * go * (1.f - go);
-                dc_carry = dc * gf;
-                g[0] = dg4[0]; g[Dd] = dg4[1]; g[2 * Dd] = dg4[2]; g[3 * Dd] = dg4[3];
+                s_dg16[tid] = f2bf_bits(d0); s_dg16[Dd + tid] = f2bf_bits(d1);
+                s_dg16[2 * Dd + tid] = f2bf_bits(d2); s_dg16[3 * Dd + tid] = f2bf_bits(d3);
             }
-            // record layout: local row r = g*UPW + ul; pairs (ul, ul+1) of the same gate by even lanes
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float nb = __shfl_down(dg4[g4], 1);
-                if ((lane & 1) == 0 && lane < ((p.UPW + 1) & ~1)) {
-                    u64* dst = out + (long)j * p.GG2 + ((g4 * ((p.UPW + 1) & ~1) + lane) >> 1);
-                    if (local) publish<true>(dst, pack2(dg4[g4], nb, want)); else publish<false>(dst, pack2(dg4[g4], nb, want));
-                }
-            }
-            if (lane == 0 && 4 * (((p.UPW + 1) & ~1) >> 1) < p.GG2) {
-                u64* dst = out + (long)j * p.GG2 + p.GG2 - 1;
-                if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
+            if (uown) {
+                float* go = p.dgates + row * 4 * Dd + tid;
+                go[0] = d0; go[Dd] = d1; go[2 * Dd] = d2; go[3 * Dd] = d3;
             }
         }
         DP_MARK(1)
-        __syncthreads();                                                // H1: s_gst holds every workgroup's gate gradients
+        __syncthreads();                                                // Ba
         DP_MARK(2)
-        // scatter the records into the global row order of dgates: row = g*Dd + i*UPW + ul
-        {
-            const int UP2 = (p.UPW + 1) & ~1;
-            for (int i = tid; i < NT * 4 * UP2; i += nct) {
-                const int prod = i / (4 * UP2), r = i - prod * 4 * UP2, g4 = r / UP2, ul = r - g4 * UP2;
-                const int unit = prod * p.UPW + ul;
-                if (ul < p.UPW && unit < Dd) s_dg[g4 * Dd + unit] = s_gst[prod * p.GG2 * 2 + r];
-            }
-        }
-        cbar(&s_bar, gen, ncw);
+        // ---- P1: dctx slice and the recurrent part of dh_{t-1} for the own units
+        DPB_P1()
         DP_MARK(3)
-        // ---- P1: dctx slice and the recurrent part of dh_{t-1} for the own units: rows of [W_ih | W_hh]^T (bf16, L2) . dgates
-        {
-            float acc[NOUTW];
-            int xrow[NOUTW];
-#pragma unroll
-            for (int o = 0; o < NOUTW; ++o) {
-                acc[o] = 0.f;
-                const int oo = wave + ncw * o;
-                int x = 0;
-                if (oo < p.CPW) x = Dd + min(c_base + oo, E - 1);
-                else x = XW + min(u_base + (oo - p.CPW), Dd - 1);
-                xrow[o] = (oo < nout) ? x : Dd;
-            }
-            const int nchunk = R4 >> 3;
-            for (int ch0 = lane; ch0 < nchunk; ch0 += 64) {
-                uint4 wv[NOUTW];
-#pragma unroll
-                for (int o = 0; o < NOUTW; ++o) wv[o] = *reinterpret_cast<const uint4*>(p.wcatT16 + (long)xrow[o] * R4 + 8 * ch0);
-                const float4 ga = *reinterpret_cast<const float4*>(s_dg + 8 * ch0);
-                const float4 gb = *reinterpret_cast<const float4*>(s_dg + 8 * ch0 + 4);
-#pragma unroll
-                for (int o = 0; o < NOUTW; ++o) {
-                    const uint4 w4 = wv[o];
-                    acc[o] += __uint_as_float(w4.x << 16) * ga.x + __uint_as_float(w4.x & 0xffff0000u) * ga.y +
-                              __uint_as_float(w4.y << 16) * ga.z + __uint_as_float(w4.y & 0xffff0000u) * ga.w +
-                              __uint_as_float(w4.z << 16) * gb.x + __uint_as_float(w4.z & 0xffff0000u) * gb.y +
-                              __uint_as_float(w4.w << 16) * gb.z + __uint_as_float(w4.w & 0xffff0000u) * gb.w;
-                }
-            }
-#pragma unroll
-            for (int o = 0; o < NOUTW; ++o) {
-                const float sv = wave_sum(acc[o]);
-                const int oo = wave + ncw * o;
-                if (lane == 0 && oo < nout) s_out[oo] = sv;
-            }
-        }
-        cbar(&s_bar, gen, ncw);
-        {
-            // dctx slice record + global dxin (context part); recurrent dh for the next (earlier) step
-            const int CP2 = (p.CPW + 1) & ~1;
-            if (tid < CP2 / 2) {
-                const float v0 = (2 * tid < p.CPW && c_base + 2 * tid < E) ? s_out[2 * tid] : 0.f;
-                const float v1 = (2 * tid + 1 < p.CPW && c_base + 2 * tid + 1 < E) ? s_out[2 * tid + 1] : 0.f;
-                u64* dst = out + offC + (long)j * p.CG2 + tid;
-                if (local) publish<true>(dst, pack2(v0, v1, want)); else publish<false>(dst, pack2(v0, v1, want));
-                if (2 * tid < p.CPW && c_base + 2 * tid < E) p.dxin[row * XW + Dd + c_base + 2 * tid] = v0;
-                if (2 * tid + 1 < p.CPW && c_base + 2 * tid + 1 < E) p.dxin[row * XW + Dd + c_base + 2 * tid + 1] = v1;
-            } else if (tid == CP2 / 2 && CP2 / 2 < p.CG2) {
-                u64* dst = out + offC + (long)j * p.CG2 + p.CG2 - 1;
-                if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
-            }
-            if (tid < p.UPW) s_dhn[tid] = s_out[p.CPW + tid];
-        }
-        // operands of the sweep that do not depend on the hand-offs
-        const float qa = p.s.q[row * A + ac];
-        for (int i = tid; i < Kn * TE; i += nct) {
-            const int k = i / TE, f = i - k * TE;
-            s_cv[f * KP + k] = (tau0 + f < Tp) ? p.s.conv[(row * Kn + k) * Tp + tau0 + f] : 0.f;
-        }
+        __syncthreads();                                                // Bb
         DP_MARK(4)
-        __syncthreads();                                                // H2: s_dctx holds the dctx slices of all workgroups
+        // ---- C record {dctx slice | dh_rec slice} + global dxin (context part)
+        if (tid < p.CG2) {
+            float v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * tid + h;
+                const bool ok = (i < p.CPW) ? (c_base + i < E) : (i < nout && u_base + (i - p.CPW) < Dd);
+                v[h] = ok ? s_out[min(i, RPWB * 8 - 1)] : 0.f;
+                if (i < p.CPW && c_base + i < E) p.dxin[row * XW + Dd + c_base + i] = v[h];
+            }
+            u64* dst = out + offC + (long)j * p.CG2 + tid;
+            if (local) publish<true>(dst, pack2(v[0], v[1], want)); else publish<false>(dst, pack2(v[0], v[1], want));
+        }
+        // ---- operands of P2/P3 that do not depend on the hand-offs: requested now, used behind H2
+        const float qa = p.s.q[row * A + ac];
+        const int f2 = tid >> 3, part = tid & 7;                         // P2: 8 threads per frame
+        uint4 x[10];
+        {
+            const unsigned short* er = p.enc16 + ((long)b * Tp + min(tau0 + min(f2, TE - 1), tmax)) * E;
+#pragma unroll
+            for (int u = 0; u < 10; ++u) x[u] = *reinterpret_cast<const uint4*>(er + 8 * min(part + 8 * u, (E >> 3) - 1));
+        }
+        float ctx2[2], attv[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ctx2[h] = p.s.xin[row * XW + Dd + min(tid + nct * h, E - 1)];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) attv[h] = p.s.att[row * Tp + min(tid + nct * h, Tp - 1)];
+        const float attf = p.s.att[row * Tp + min(tau0 + min(f2, TE - 1), Tp - 1)];
+        {
+            float c0, c1;
+            const int i0 = tid, i1 = tid + nct;
+            const int k0 = min(i0, Kn * TE - 1) / TE, fr0 = min(i0, Kn * TE - 1) - k0 * TE;
+            const int k1 = min(i1, Kn * TE - 1) / TE, fr1 = min(i1, Kn * TE - 1) - k1 * TE;
+            c0 = p.s.conv[(row * Kn + k0) * Tp + min(tau0 + fr0, Tp - 1)];
+            c1 = p.s.conv[(row * Kn + k1) * Tp + min(tau0 + fr1, Tp - 1)];
+            if (i0 < Kn * TE) s_cv[fr0 * KP + k0] = (tau0 + fr0 < Tp) ? c0 : 0.f;
+            if (i1 < Kn * TE) s_cv[fr1 * KP + k1] = (tau0 + fr1 < Tp) ? c1 : 0.f;
+        }
         DP_MARK(5)
+        __syncthreads();                                                // H2: s_crec holds the C records of all workgroups
+        DP_MARK(6)
         // ---- P2: dattn of the tile, dot over the utterance, de
         {
-            const int CG2f = 2 * p.CG2;
-            // the gathered slices as one contiguous vector (the records are CPW floats wide)
-            for (int e = tid; e < E; e += nct) { const int i = e / p.CPW; s_dcx[e] = s_dctx[i * CG2f + (e - i * p.CPW)]; }
+            for (int e = tid; e < E; e += nct) { const int i = e / p.CPW; s_dcx[e] = s_crec[i * CG2f + (e - i * p.CPW)]; }
             cbar(&s_bar, gen, ncw);
-            auto dctx_at = [&](int e) { return s_dcx[e]; };
-            const int f = tid >> 3, part = tid & 7;
             float v = 0.f;
-            if (f < TE) {
-                const unsigned short* er = p.enc16 + ((long)b * Tp + min(tau0 + f, tmax)) * E;
-                uint4 x[10];
 #pragma unroll
-                for (int u = 0; u < 10; ++u) x[u] = *reinterpret_cast<const uint4*>(er + 8 * min(part + 8 * u, (E >> 3) - 1));
-#pragma unroll
-                for (int u = 0; u < 10; ++u) {
-                    const int ch = part + 8 * u;
-                    if (8 * ch < E) {
-                        const int e0 = 8 * ch;
-                        v += __uint_as_float(x[u].x << 16) * dctx_at(e0) + __uint_as_float(x[u].x & 0xffff0000u) * dctx_at(e0 + 1) +
-                             __uint_as_float(x[u].y << 16) * dctx_at(e0 + 2) + __uint_as_float(x[u].y & 0xffff0000u) * dctx_at(e0 + 3) +
-                             __uint_as_float(x[u].z << 16) * dctx_at(e0 + 4) + __uint_as_float(x[u].z & 0xffff0000u) * dctx_at(e0 + 5) +
-                             __uint_as_float(x[u].w << 16) * dctx_at(e0 + 6) + __uint_as_float(x[u].w & 0xffff0000u) * dctx_at(e0 + 7);
-                    }
+            for (int u = 0; u < 10; ++u) {
+                const int ch = part + 8 * u;
+                if (8 * ch < E) {
+                    const float4 da = *reinterpret_cast<const float4*>(s_dcx + 8 * ch), db = *reinterpret_cast<const float4*>(s_dcx + 8 * ch + 4);
+                    v += __uint_as_float(x[u].x << 16) * da.x + __uint_as_float(x[u].x & 0xffff0000u) * da.y +
+                         __uint_as_float(x[u].y << 16) * da.z + __uint_as_float(x[u].y & 0xffff0000u) * da.w +
+                         __uint_as_float(x[u].z << 16) * db.x + __uint_as_float(x[u].z & 0xffff0000u) * db.y +
+                         __uint_as_float(x[u].w << 16) * db.z + __uint_as_float(x[u].w & 0xffff0000u) * db.w;
                 }
             }
             v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
             float dot = 0.f;
-            for (int e = tid; e < E; e += nct) dot += dctx_at(e) * p.s.xin[row * XW + Dd + e];
-            if (t < L - 1) for (int tau = tid; tau < len; tau += nct) dot += p.s.att[row * Tp + tau] * s_dn[tau];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) if (tid + nct * h < E) dot += ctx2[h] * s_dcx[tid + nct * h];
+            if (s > 0) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int tau = tid + nct * h;
+                    if (tau < len) { const int i = tau / TE; dot += attv[h] * s_nrec[i * NG2f + (tau - i * TE)]; }
+                }
+            }
             dot = wave_sum(dot);
             if (lane == 0) s_red[wave] = dot;
             cbar(&s_bar, gen, ncw);
             dot = 0.f;
             for (int w = 0; w < ncw; ++w) dot += s_red[w];
-            if (f < TE && part == 0) {
-                const int tau = tau0 + f;
-                const float dat = v + ((t < L - 1 && tau < TW) ? s_dn[min(tau, TW - 1)] : 0.f);
-                s_de[f] = (tau < len) ? p.s.att[row * Tp + tau] * (dat - dot) / d.temperature : 0.f;
+            if (f2 < TE && part == 0) {
+                const int tau = tau0 + f2;
+                const float dat = v + ((s > 0) ? s_nrec[j * NG2f + f2] : 0.f);
+                s_de[f2] = (tau < len) ? attf * (dat - dot) / d.temperature : 0.f;
             }
         }
         cbar(&s_bar, gen, ncw);
-        DP_MARK(6)
-        // ---- P3: energy backward sweep; thread a owns column a of all TE frames
+        DP_MARK(7)
+        // ---- P3: energy backward sweep; thread a owns column a of all TE frames; dkey by fire-and-forget atomics
         float dqa = 0.f;
-        // dkey tile: read-modify-write in global memory, which here means this XCD's L2 (the same workgroup touches the same
-        // 48 KB every step; a register-resident tile made the fully unrolled sweep spill ~800 registers)
-        float* dkp = p.dkey + ((long)b * Tp + tau0) * A + ac;
-#pragma unroll 1
-        for (int f0 = 0; f0 < TE; f0 += 8) {
-            float dk[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dk[i] = dkp[(long)min(f0 + i, max(min(TE, len - tau0), 1) - 1) * A];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int f = f0 + i;
+        {
+            float* dkp = p.dkey + ((long)b * Tp + tau0) * A + ac;
+#pragma unroll 4
+            for (int f = 0; f < TE; ++f) {
                 float cvv[KP];
 #pragma unroll
                 for (int k4 = 0; k4 < KP; k4 += 4) {
@@ -997,11 +1013,11 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                 dqa += du;
 #pragma unroll
                 for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * cvv[k];
-                if (aok && tau0 + f < len) dkp[(long)f * A] = dk[i] + du;
+                if (aok && tau0 + f < len) atomicAdd(dkp + (long)f * A, du);
                 if (aok) s_dl[f * AP + a] = f2bf_bits(dl);
             }
+            if (tid == 0) { for (int f = 0; f < TE; ++f) dbg += s_de[f]; }
         }
-        if (tid == 0) { for (int f = 0; f < TE; ++f) dbg += s_de[f]; }
         // query-gradient partial of this tile, already times (1 - q^2): pairs (a, a+1) by even lanes
         {
             const float mine = aok ? dqa * (1.f - qa * qa) : 0.f;
@@ -1012,42 +1028,52 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             }
         }
         cbar(&s_bar, gen, ncw);
-        DP_MARK(7)
-        // ---- P4: dconv[f][k] = sum_a dl[f][a] * W_proj[a][k]  (thread per (f, k))
-        for (int o = tid; o < TE * Kn; o += nct) {
-            const int k = o / TE, f = o - k * TE;
-            const unsigned short* dlr = s_dl + f * AP;
-            const float* wr = s_wpT + k * AP;
-            float v0 = 0.f, v1 = 0.f;
-            for (int x = 0; x < AP; x += 8) {
-                const uint4 d4 = *reinterpret_cast<const uint4*>(dlr + x);
-                const float4 wa = *reinterpret_cast<const float4*>(wr + x), wb = *reinterpret_cast<const float4*>(wr + x + 4);
-                v0 += __uint_as_float(d4.x << 16) * wa.x + __uint_as_float(d4.x & 0xffff0000u) * wa.y +
-                      __uint_as_float(d4.y << 16) * wa.z + __uint_as_float(d4.y & 0xffff0000u) * wa.w;
-                v1 += __uint_as_float(d4.z << 16) * wb.x + __uint_as_float(d4.z & 0xffff0000u) * wb.y +
-                      __uint_as_float(d4.w << 16) * wb.z + __uint_as_float(d4.w & 0xffff0000u) * wb.w;
+        DP_MARK(8)
+        // ---- P4: dconv (TE x Kn) = dl (TE x A) . W_proj (A x Kn) on the matrix cores, one 16-frame tile per wave
+        if (wave < MT) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int m = lane & 15, kq = lane >> 4;
+            const unsigned short* ar = s_dl + min(16 * wave + m, TE - 1) * AP + 8 * kq;
+            const unsigned short* br = s_wp16 + m * AP + 8 * kq;
+            const int nks = (A + 31) >> 5;
+            for (int ks = 0; ks < nks; ++ks) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(ar + 32 * ks);
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(br + 32 * ks);
+                acc = mma16(av, bv, acc);
             }
-            const int tau = tau0 + f;
-            const float v = (tau < len) ? v0 + v1 : 0.f;
-            if (tau < Tp) p.s.conv[(row * Kn + k) * Tp + tau] = v;     // dconv over the saved conv (for d W_conv after the loop)
-            s_out[0] = 0.f;                                             // (keeps s_out initialised for the pad below)
-            // record order = [k][f]: pairs of frames
-            const float nb = __shfl_down(v, 1);
-            if ((f & 1) == 0) {
-                u64* dst = out + offV + (long)j * p.VG2 + (o >> 1);
-                if (local) publish<true>(dst, pack2(v, (f + 1 < TE) ? nb : 0.f, want)); else publish<false>(dst, pack2(v, (f + 1 < TE) ? nb : 0.f, want));
+            if (m < Kn) {
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    const int f = 16 * wave + 4 * kq + i;
+                    if (f < TE) {
+                        const float v0 = (tau0 + f < len) ? acc[i] : 0.f, v1 = (tau0 + f + 1 < len) ? acc[i + 1] : 0.f;
+                        // dconv over the saved conv (for d W_conv after the loop)
+                        if (tau0 + f < Tp) p.s.conv[(row * Kn + m) * Tp + tau0 + f] = v0;
+                        if (tau0 + f + 1 < Tp) p.s.conv[(row * Kn + m) * Tp + tau0 + f + 1] = v1;
+                        u64* dst = out + offV + (long)j * p.VG2 + ((m * TE + f) >> 1);      // record order [k][f]
+                        if (local) publish<true>(dst, pack2(v0, v1, want)); else publish<false>(dst, pack2(v0, v1, want));
+                    }
+                }
             }
         }
-        if (tid == 0 && (TE * Kn + 1) / 2 < p.VG2) {
+        if (tid == nct - 1 && (TE * Kn + 1) / 2 < p.VG2) {
             u64* dst = out + offV + (long)j * p.VG2 + p.VG2 - 1;
             if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
         }
-        DP_MARK(8)
-        __syncthreads();                                                // H3: dq partials and dconv tiles of all workgroups
         DP_MARK(9)
+        __syncthreads();                                                // H3: dq partials and dconv tiles of all workgroups
+        DP_MARK(10)
         // ---- P5: dq (sum over tiles), its part of dh_{t-1}, datt_next of the tile
+        if (t > 0) {
+            // operands of the next step's cell backward
+            const long r1 = row - 1;
+            const float* g = p.s.gates + r1 * 4 * Dd + uc;
+            pgi = g[0]; pgf = g[Dd]; pgg = g[2 * Dd]; pgo = g[3 * Dd];
+            pct = p.s.cs[r1 * Dd + uc];
+            pcp = (t > 1) ? p.s.cs[(r1 - 1) * Dd + uc] : 0.f;
+            pdh = p.dhs[r1 * Dd + uc];
+        }
         {
-            const int QG2f = 2 * p.QG2;
             float dqv = 0.f;
             if (aok) for (int i = 0; i < NT; ++i) dqv += s_qst[i * QG2f + a];
             if (aok) s_dq[a] = dqv;
@@ -1077,43 +1103,46 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                 float* o4 = s_pt + (long)(pz * Kn + k) * TE + 4 * ig;
                 o4[0] = a0; o4[1] = a1; o4[2] = a2; o4[3] = a3;
             }
-        }
-        cbar(&s_bar, gen, ncw);
-        if (t > 0) {
-            // dh_{t-1}[unit] += sum_a dq[a] * W_q[a][unit]: wave w takes units w, w+ncw, ..; lanes over a
-            for (int ul = wave; ul < p.UPW; ul += ncw) {
-                const int unit = min(u_base + ul, Dd - 1);
-                float wq[5];
-#pragma unroll
-                for (int k5 = 0; k5 < 5; ++k5) wq[k5] = p.wqT[(long)unit * A + min(lane + 64 * k5, A - 1)];
-                float acc = 0.f;
-#pragma unroll
-                for (int k5 = 0; k5 < 5; ++k5) if (lane + 64 * k5 < A) acc += s_dq[lane + 64 * k5] * wq[k5];
-                acc = wave_sum(acc);
-                if (lane == 0) s_dhn[ul] += acc;
-            }
+            cbar(&s_bar, gen, ncw);                                     // s_dq, s_pt complete
+            // query part of dh_{t-1}: sum_a dq[a] * W_q[a][unit] for the own units (weights in registers)
             {
-                const int nitem = Kn * (TE / 4);
-                const int parts = max(1, min(4, nct / nitem));
-                float v = 0.f;
-                if (tid < TE) for (int r = 0; r < parts * Kn; ++r) v += s_pt[(long)r * TE + tid];
-                const float nb = __shfl_down(v, 1);
-                if (tid < TE && (tid & 1) == 0) {
-                    u64* dst = out + offN + (long)j * p.NG2 + (tid >> 1);
-                    if (local) publish<true>(dst, pack2(v, (tid + 1 < TE) ? nb : 0.f, want)); else publish<false>(dst, pack2(v, (tid + 1 < TE) ? nb : 0.f, want));
-                }
-                if (tid == 0 && TE / 2 < p.NG2) {
-                    u64* dst = out + offN + (long)j * p.NG2 + p.NG2 - 1;
-                    if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
+                float dqr[5];
+#pragma unroll
+                for (int k5 = 0; k5 < 5; ++k5) dqr[k5] = (lane + 64 * k5 < A) ? s_dq[min(lane + 64 * k5, A - 1)] : 0.f;
+#pragma unroll
+                for (int i = 0; i < UQW; ++i) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k5 = 0; k5 < 5; ++k5) acc += dqr[k5] * wq[i][k5];
+                    acc = wave_sum(acc);
+                    const int ul = wave + ncw * i;
+                    if (lane == 0 && ul < p.UPW) s_hq[ul] = (u_base + ul < Dd) ? acc : 0.f;
                 }
             }
+            cbar(&s_bar, gen, ncw);                                     // s_hq complete
+            // N record {datt_next tile | dh_q slice}
+            if (tid < p.NG2) {
+                const int nitem2 = Kn * (TE / 4);
+                const int parts2 = max(1, min(4, nct / nitem2));
+                float v[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * tid + h;
+                    float sv = 0.f;
+                    if (i < TE) { for (int r = 0; r < parts2 * Kn; ++r) sv += s_pt[(long)r * TE + i]; }
+                    else if (i - TE < p.UPW) sv = s_hq[i - TE];
+                    v[h] = sv;
+                }
+                u64* dst = out + offN + (long)j * p.NG2 + tid;
+                if (local) publish<true>(dst, pack2(v[0], v[1], want)); else publish<false>(dst, pack2(v[0], v[1], want));
+            }
         }
-        DP_MARK(10)
-        __syncthreads();                                                // H4: s_dn holds datt_next for the next step
         DP_MARK(11)
+        __syncthreads();                                                // H4: s_nrec holds the N records for the next step
+        DP_MARK(12)
     }
     DP_DUMP
-    // ---- results that were accumulated on chip: dkey tile and the slot of this workgroup
+    // ---- results that were accumulated on chip: the slot of this workgroup
     if (aok) {
         float* sl = p.slots + ((long)b * NT + j) * p.slot;
         sl[a] = dwg;
@@ -1123,31 +1152,33 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     if (tid == 0) p.slots[((long)b * NT + j) * p.slot + A * (1 + Kn)] = dbg;
 }
 
-struct PersistPlanB { bool ok; int TE, NT, UPW, CPW, R4, GG2, CG2, QG2, VG2, NG2; size_t lds, status_bytes, xbuf_bytes, w16_bytes, total; };
+struct PersistPlanB { bool ok; int TE, NT, UPW, CPW, R4, CG2, QG2, VG2, NG2; size_t lds, status_bytes, xbuf_bytes, w16_bytes, dg_bytes, total; };
 
 PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
     PersistPlanB pl{};
     pl.ok = false;
-    if (d.NL != 1 || d.B > 64 || d.A > 320 || d.Kn > 10 || (d.E & 7) != 0 || d.E > 640 || (d.A & 1) != 0) return pl;
+    if (d.NL != 1 || d.B > 64 || d.A > 320 || d.A < 16 || d.Kn > 10 || (d.E & 7) != 0 || (d.A & 1) != 0 || d.Dd > 64 * KCHB || d.L < 1) return pl;
     const int cpx = cdiv(d.B, 8);
+    const int ncw = cdiv(d.A, 64), nct = 64 * ncw;
+    if (d.Dd > nct || d.E > 2 * nct || d.E > 640 || d.Tp > 4 * nct) return pl;
     int TE = 0;
     const int cand[] = {16, 40};
-    for (int i = 0; i < 2; ++i) { const int nt = cdiv(d.Tp, cand[i]); if (nt <= 30 && cpx * nt <= 32) { TE = cand[i]; break; } }
+    for (int i = 0; i < 2; ++i) { const int nt = cdiv(d.Tp, cand[i]); if (nt <= 30 && cpx * nt <= 32 && 8 * cand[i] <= nct) { TE = cand[i]; break; } }
     if (!TE) return pl;
     pl.TE = TE; pl.NT = cdiv(d.Tp, TE);
     pl.UPW = cdiv(d.Dd, pl.NT); pl.CPW = cdiv(d.E, pl.NT);
-    const int ncw = cdiv(d.A, 64);
-    if (pl.UPW > 64 || pl.UPW + pl.CPW > NOUTW * ncw || ncw > 5 || 8 * TE > 64 * ncw) return pl;   // P2 maps 8 threads to a frame
+    if (pl.UPW > UQW * ncw || pl.UPW + pl.CPW > RPWB * (ncw + NPB) || d.Kn * TE > 2 * nct || (TE + pl.UPW + 1) / 2 + 1 > nct) return pl;
     pl.R4 = (4 * d.Dd + 7) & ~7;
     auto even = [](int x) { return (x + 1) & ~1; };
-    pl.GG2 = even(4 * (even(pl.UPW) / 2)); pl.CG2 = even(even(pl.CPW) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even(TE / 2);
-    const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.R4, pl.GG2, pl.CG2, pl.QG2, pl.NG2);
+    pl.CG2 = even((pl.CPW + pl.UPW + 1) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even((TE + pl.UPW + 1) / 2);
+    const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.CG2, pl.QG2, pl.NG2);
     pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
     if (pl.lds > 150 * 1024) return pl;
     pl.status_bytes = 4096;
-    pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.GG2 + pl.CG2 + pl.QG2 + pl.VG2 + pl.NG2) * sizeof(u64));
+    pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.CG2 + pl.QG2 + pl.VG2 + pl.NG2) * sizeof(u64));
     pl.w16_bytes = align_up256((size_t)(d.Dd + d.E + d.Dd) * pl.R4 * 2);
-    pl.total = pl.status_bytes + pl.xbuf_bytes + pl.w16_bytes;
+    pl.dg_bytes = align_up256((size_t)d.B * d.L * 4 * d.Dd * sizeof(float));
+    pl.total = pl.status_bytes + pl.xbuf_bytes + pl.w16_bytes + pl.dg_bytes;
     pl.ok = true;
     return pl;
 }
@@ -1167,9 +1198,10 @@ int dec_bwd_persist_tiles(const asr_dec_dims_t& d) { const PersistPlanB pl = per
 
 // Returns ASR_OK when the whole backward loop was launched, 1 when there is no persistent plan, negative on error.
 // dhs: (B,L,Dd) gradient wrt h from the output layer; wcatT: ((Dd+E+Dd) x 4Dd) fp32 transposed [W_ih | W_hh]; wqT: (Dd x A).
+// *dgates_out: (B*L, 4Dd) gate pre-activation gradients inside `work`.
 int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const int64_t* enc_len,
                        const float* dhs, float* dxin, float* dq, float* dkey, float* slots, int slot, const float* wcatT, const float* wqT,
-                       void* work, size_t work_bytes, hipStream_t st) {
+                       void* work, size_t work_bytes, float** dgates_out, hipStream_t st) {
     if (g_persist_bwd < 0) { const char* e = getenv("ASR_DEC_PERSIST_BWD"); g_persist_bwd = (e && e[0] == '0') ? 0 : 1; }
     const PersistPlanB pl = persist_plan_b(d);
     if (!g_persist_bwd || !pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv || !s.enc16) return 1;
@@ -1177,13 +1209,16 @@ int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
     unsigned* status = (unsigned*)base;
     u64* xbuf = (u64*)(base + pl.status_bytes);
     unsigned short* w16 = (unsigned short*)(base + pl.status_bytes + pl.xbuf_bytes);
+    float* dgates = (float*)(base + pl.status_bytes + pl.xbuf_bytes + pl.w16_bytes);
+    *dgates_out = dgates;
     hipMemsetAsync(work, 0, pl.status_bytes + pl.xbuf_bytes, st);
     hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3(512), dim3(256), 0, st, wcatT, w16, d.Dd + d.E + d.Dd, 4 * d.Dd, pl.R4);
     static unsigned epoch_counter = 7;
-    static int allow = -1;
+    static int allow = -1, delay = -1;
     if (allow < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); allow = (e && e[0] == '0') ? 0 : 1; }
-    PB p{d, w, s, (const unsigned short*)s.enc16, enc_len, dhs, dxin, dq, dkey, slots, w16, wqT, xbuf, status,
-         slot, pl.NT, pl.UPW, pl.CPW, pl.R4, pl.GG2, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, epoch_counter++};
+    if (delay < 0) { const char* e = getenv("ASR_DEC_BWD_POLL_DELAY"); delay = e ? atoi(e) : 0; }
+    PB p{d, w, s, (const unsigned short*)s.enc16, enc_len, dhs, dxin, dq, dkey, slots, dgates, w16, wqT, xbuf, status,
+         slot, pl.NT, pl.UPW, pl.CPW, pl.R4, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, epoch_counter++, delay};
     const int cpx = cdiv(d.B, 8), ncw = cdiv(d.A, 64);
     const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
 #define DPB_LAUNCH(KN_, TE_)                                                                                                    \

@@ -607,13 +607,27 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
 namespace {
 
 constexpr int NPB = 3;            // polling waves of the backward kernel
-constexpr int RPWB = 8;           // rows of the transposed-weight product per wave
+constexpr int RCB = 6, RPB = 12;  // rows of the transposed-weight product per compute wave / per polling wave
+constexpr int RPWB = 12;          // (s_out is sized for RPWB * 8 >= RCB * ncw + RPB * NPB outputs)
 constexpr int KCHB = 5;           // 4-column chunks of the gate-gradient vector per lane (4*Dd <= 1280)
 constexpr int UQW = 4;            // hidden units per compute wave in the query-part product
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
 __device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_, a), __builtin_bit_cast(bf16x2_, b), c, false);
+}
+
+// wave-wide sum on the DPP path (quad swaps, mirrors, row broadcasts: 6 VALU steps, no LDS permutes); uniform result
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define DPB_STEP(CTRL, RMASK) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false));
+    DPB_STEP(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    DPB_STEP(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    DPB_STEP(0x141, 0xf)     // row_half_mirror
+    DPB_STEP(0x140, 0xf)     // row_mirror
+    DPB_STEP(0x142, 0xa)     // row_bcast15 -> rows 1, 3
+    DPB_STEP(0x143, 0xc)     // row_bcast31 -> rows 2, 3
+#undef DPB_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 struct PB {
@@ -640,12 +654,14 @@ struct PB {
 };
 
 // LDS carve of dec_bwd_persist, shared by the kernel and the host plan (float offsets follow the bf16 arrays).
-struct BCarve { int AP, DW, key, dl, wp16, dg16, shorts; int wc, crec, qst, nrec, dcp, cv, de, out, hq, pt, dcx, dq, floats; };
+struct BCarve { int AP, DW, PADL, WT, key, dl, wp16, dg16, shorts; int wc, crec, qst, nrec, dcp, cv, de, out, hq, pt, dcx, dq, floats; };
 __host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn, int Ks, int NT, int UPW, int CG2, int QG2, int NG2) {
     BCarve c;
     int ap8 = 4 * ((A + 31) / 32); if ((ap8 & 1) == 0) ++ap8;
     c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: >= 32*ceil(A/32), odd in 16-byte units
-    c.DW = (NT * TE + 2 * Ks + 8 + 3) & ~3;             // zero-padded dconv row
+    c.PADL = Ks + 8 + ((4 - ((2 * Ks) & 3)) & 3);       // left zero pad of a dconv row: PADL + Ks is a multiple of 4
+    c.DW = (c.PADL + NT * TE + Ks + 8 + 3) & ~3;        // zero-padded dconv row
+    c.WT = (2 * Ks + 1 + 3) & ~3;                       // zero-padded filter row
     int o = 0;
     c.key = o; o += (TE * A + 7) & ~7;
     c.dl = o; o += TE * c.AP;
@@ -653,7 +669,7 @@ __host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn
     c.dg16 = o; o += 64 * KCHB * 4;
     c.shorts = o;
     o = 0;
-    c.wc = o; o += (Kn * (2 * Ks + 1) + 3) & ~3;
+    c.wc = o; o += Kn * c.WT;
     c.crec = o; o += NT * CG2 * 2;
     c.qst = o; o += NT * QG2 * 2;
     c.nrec = o; o += NT * NG2 * 2 + 8;
@@ -694,21 +710,33 @@ __device__ __forceinline__ void poll_copy(const u64* src, int n16, float* dst, i
     }
 }
 
-// rows of [W_ih(ctx) | W_hh]^T (registers) . dgates (bf16, LDS): output oo = wave + nw*o -> s_out[oo]
-#define DPB_P1()                                                                                                       \
+// rows of [W_ih(ctx) | W_hh]^T (registers) . dgates (bf16, LDS): output oo = BASE + STRIDE*o, o < NR -> s_out[oo]
+#define DPB_P1(NR, BASE, STRIDE)                                                                                       \
     {                                                                                                                  \
-        float acc_[RPWB];                                                                                              \
-        _Pragma("unroll") for (int o = 0; o < RPWB; ++o) acc_[o] = 0.f;                                                \
+        float acc_[NR];                                                                                                \
+        _Pragma("unroll") for (int o = 0; o < NR; ++o) acc_[o] = 0.f;                                                  \
         _Pragma("unroll") for (int k = 0; k < KCHB; ++k) {                                                             \
             const uint2 g_ = *reinterpret_cast<const uint2*>(s_dg16 + 4 * (lane + 64 * k));                            \
-            _Pragma("unroll") for (int o = 0; o < RPWB; ++o) {                                                         \
+            _Pragma("unroll") for (int o = 0; o < NR; ++o) {                                                           \
                 acc_[o] = dot2bf(wreg[o][k].x, g_.x, acc_[o]);                                                         \
                 acc_[o] = dot2bf(wreg[o][k].y, g_.y, acc_[o]);                                                         \
             }                                                                                                          \
         }                                                                                                              \
-        _Pragma("unroll") for (int o = 0; o < RPWB; ++o) {                                                             \
-            const float sv_ = wave_sum(acc_[o]);                                                                       \
-            if (lane == 0 && wave + nw * o < nout) s_out[wave + nw * o] = sv_;                                         \
+        _Pragma("unroll") for (int o = 0; o < NR; ++o) {                                                               \
+            const float sv_ = wave_sum_dpp(acc_[o]);                                                                   \
+            if (lane == 0 && (BASE) + (STRIDE) * o < nout) s_out[(BASE) + (STRIDE) * o] = sv_;                         \
+        }                                                                                                              \
+    }
+// loads the rows of this wave (same mapping) into wreg[NR][KCHB]
+#define DPB_WLOAD(NR, BASE, STRIDE)                                                                                    \
+    _Pragma("unroll") for (int o = 0; o < NR; ++o) {                                                                   \
+        const int oo = (BASE) + (STRIDE) * o;                                                                          \
+        int x = (oo < p.CPW) ? Dd + min(c_base + oo, E - 1) : XW + min(u_base + (oo - p.CPW), Dd - 1);                  \
+        if (oo >= nout) x = Dd;                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < KCHB; ++k) {                                                             \
+            const int col = 4 * (lane + 64 * k);                                                                       \
+            const uint2 v = *reinterpret_cast<const uint2*>(p.wcatT16 + (long)x * R4 + min(col, R4 - 4));              \
+            wreg[o][k] = (col < R4) ? v : make_uint2(0u, 0u);                                                          \
         }                                                                                                              \
     }
 
@@ -732,7 +760,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     const int len = min((int)p.enc_len[b], Tp);
     const int tmax = max(len - 1, 0);
     const BCarve cv_ = bwd_carve(TE, KP, A, E, Kn, Ks, NT, p.UPW, p.CG2, p.QG2, p.NG2);
-    const int AP = cv_.AP, DW = cv_.DW;
+    const int AP = cv_.AP, DW = cv_.DW, PADL = cv_.PADL, WT = cv_.WT;
     const int TW = NT * TE;                                             // padded attention row
     const int CG2f = 2 * p.CG2, NG2f = 2 * p.NG2, QG2f = 2 * p.QG2;
     // ---- LDS carve
@@ -776,40 +804,31 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         s_key[i] = f2bf_bits(p.s.key[((long)b * Tp + min(tau0 + f, tmax)) * A + a]);
     }
     for (int i = tid; i < 16 * AP; i += blockDim.x) { const int k = i / AP, a = i - k * AP; s_wp16[i] = (k < Kn && a < A) ? f2bf_bits(p.w.Wproj[a * Kn + k]) : (unsigned short)0; }
-    for (int i = tid; i < Kn * taps; i += blockDim.x) s_wc[i] = p.w.Wconv[i];
+    for (int i = tid; i < Kn * WT; i += blockDim.x) { const int k = i / WT, jj = i - k * WT; s_wc[i] = (jj < taps) ? p.w.Wconv[k * taps + jj] : 0.f; }
     for (int i = tid; i < 64 * KCHB * 4; i += blockDim.x) s_dg16[i] = 0;
     for (int i = tid; i < NT * NG2f + 8; i += blockDim.x) s_nrec[i] = 0.f;
     for (int i = tid; i < NT * CG2f; i += blockDim.x) s_crec[i] = 0.f;
     for (int i = tid; i < Kn * DW; i += blockDim.x) s_dcp[i] = 0.f;
     for (int i = tid; i < TE * AP; i += blockDim.x) s_dl[i] = 0;
     for (int i = tid; i < TE * KP; i += blockDim.x) s_cv[i] = 0.f;
-    // register-resident rows of the transposed cell weights: output oo = wave + nw*o, columns 4*(lane + 64k) .. +3
     const int u_base = j * p.UPW, c_base = j * p.CPW;
     const int nout = p.CPW + p.UPW;
-    uint2 wreg[RPWB][KCHB];
-#pragma unroll
-    for (int o = 0; o < RPWB; ++o) {
-        const int oo = wave + nw * o;
-        int x = (oo < p.CPW) ? Dd + min(c_base + oo, E - 1) : XW + min(u_base + (oo - p.CPW), Dd - 1);
-        if (oo >= nout) x = Dd;
-#pragma unroll
-        for (int k = 0; k < KCHB; ++k) {
-            const int col = 4 * (lane + 64 * k);
-            const uint2 v = *reinterpret_cast<const uint2*>(p.wcatT16 + (long)x * R4 + min(col, R4 - 4));
-            wreg[o][k] = (col < R4) ? v : make_uint2(0u, 0u);
-        }
-    }
+    // rows of the transposed cell weights are register-resident: compute wave w has outputs w + ncw*o (o < RCB), polling
+    // wave pw has RCB*ncw + pw + NPB*o (o < RPB)
     __syncthreads();
 
     if (wave >= ncw) {
         // =========================== polling role ===========================
         const int gt = tid - nct, np = 64 * NPB;
+        const int obase = RCB * ncw + (wave - ncw);
+        uint2 wreg[RPB][KCHB];
+        DPB_WLOAD(RPB, obase, NPB)
         for (int t = L - 1; t >= 0; --t) {
             const int s = L - 1 - t;                                     // step counter of this launch (tags, parity)
             const u64 want = pair_want(seq_of(s), p.epoch);
             const u64* base = xb(s & 1);
             __syncthreads();                                            // Ba: s_dg16 holds the gate gradients of step t
-            DPB_P1()
+            DPB_P1(RPB, obase, NPB)
             __syncthreads();                                            // Bb: s_out complete
             poll_copy<4>(base + offC, NT * p.CG2 / 2, s_crec, gt, np, want, p.status);
             __syncthreads();                                            // H2
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
 #pragma unroll
                             for (int q4 = 0; q4 < 4; ++q4) {
                                 const int r = r0 + q4;
-                                if (r < Kn * TE) { const int kk = r / TE, f = r - kk * TE; s_dcp[kk * DW + Ks + prod * TE + f] = v[q4]; }
+                                if (r < Kn * TE) { const int kk = r / TE, f = r - kk * TE; s_dcp[kk * DW + PADL + prod * TE + f] = v[q4]; }
                             }
                         }
                 }
@@ -845,6 +864,8 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
 
     // =========================== compute role ===========================
     unsigned gen = 0;
+    uint2 wreg[RCB][KCHB];
+    DPB_WLOAD(RCB, wave, ncw)
     const int a = tid;                                                  // attention column of this thread in the sweep
     const bool aok = a < A;
     const int ac = aok ? a : A - 1;
@@ -904,7 +925,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         __syncthreads();                                                // Ba
         DP_MARK(2)
         // ---- P1: dctx slice and the recurrent part of dh_{t-1} for the own units
-        DPB_P1()
+        DPB_P1(RCB, wave, ncw)
         DP_MARK(3)
         __syncthreads();                                                // Bb
         DP_MARK(4)
@@ -936,22 +957,20 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) attv[h] = p.s.att[row * Tp + min(tid + nct * h, Tp - 1)];
         const float attf = p.s.att[row * Tp + min(tau0 + min(f2, TE - 1), Tp - 1)];
-        {
-            float c0, c1;
-            const int i0 = tid, i1 = tid + nct;
-            const int k0 = min(i0, Kn * TE - 1) / TE, fr0 = min(i0, Kn * TE - 1) - k0 * TE;
-            const int k1 = min(i1, Kn * TE - 1) / TE, fr1 = min(i1, Kn * TE - 1) - k1 * TE;
-            c0 = p.s.conv[(row * Kn + k0) * Tp + min(tau0 + fr0, Tp - 1)];
-            c1 = p.s.conv[(row * Kn + k1) * Tp + min(tau0 + fr1, Tp - 1)];
-            if (i0 < Kn * TE) s_cv[fr0 * KP + k0] = (tau0 + fr0 < Tp) ? c0 : 0.f;
-            if (i1 < Kn * TE) s_cv[fr1 * KP + k1] = (tau0 + fr1 < Tp) ? c1 : 0.f;
-        }
+        float c0, c1;                                                   // conv tile of the step (stored to LDS behind H2)
+        const int cvi0 = tid, cvi1 = tid + nct;
+        const int cvk0 = min(cvi0, Kn * TE - 1) / TE, cvf0 = min(cvi0, Kn * TE - 1) - cvk0 * TE;
+        const int cvk1 = min(cvi1, Kn * TE - 1) / TE, cvf1 = min(cvi1, Kn * TE - 1) - cvk1 * TE;
+        c0 = p.s.conv[(row * Kn + cvk0) * Tp + min(tau0 + cvf0, Tp - 1)];
+        c1 = p.s.conv[(row * Kn + cvk1) * Tp + min(tau0 + cvf1, Tp - 1)];
         DP_MARK(5)
         __syncthreads();                                                // H2: s_crec holds the C records of all workgroups
         DP_MARK(6)
         // ---- P2: dattn of the tile, dot over the utterance, de
         {
             for (int e = tid; e < E; e += nct) { const int i = e / p.CPW; s_dcx[e] = s_crec[i * CG2f + (e - i * p.CPW)]; }
+            if (cvi0 < Kn * TE) s_cv[cvf0 * KP + cvk0] = (tau0 + cvf0 < Tp) ? c0 : 0.f;
+            if (cvi1 < Kn * TE) s_cv[cvf1 * KP + cvk1] = (tau0 + cvf1 < Tp) ? c1 : 0.f;
             cbar(&s_bar, gen, ncw);
             float v = 0.f;
 #pragma unroll
@@ -976,7 +995,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                     if (tau < len) { const int i = tau / TE; dot += attv[h] * s_nrec[i * NG2f + (tau - i * TE)]; }
                 }
             }
-            dot = wave_sum(dot);
+            dot = wave_sum_dpp(dot);
             if (lane == 0) s_red[wave] = dot;
             cbar(&s_bar, gen, ncw);
             dot = 0.f;
@@ -1064,15 +1083,6 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         __syncthreads();                                                // H3: dq partials and dconv tiles of all workgroups
         DP_MARK(10)
         // ---- P5: dq (sum over tiles), its part of dh_{t-1}, datt_next of the tile
-        if (t > 0) {
-            // operands of the next step's cell backward
-            const long r1 = row - 1;
-            const float* g = p.s.gates + r1 * 4 * Dd + uc;
-            pgi = g[0]; pgf = g[Dd]; pgg = g[2 * Dd]; pgo = g[3 * Dd];
-            pct = p.s.cs[r1 * Dd + uc];
-            pcp = (t > 1) ? p.s.cs[(r1 - 1) * Dd + uc] : 0.f;
-            pdh = p.dhs[r1 * Dd + uc];
-        }
         {
             float dqv = 0.f;
             if (aok) for (int i = 0; i < NT; ++i) dqv += s_qst[i * QG2f + a];
@@ -1082,26 +1092,27 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         }
         if (t > 0) {
             // datt_next[tau'] = sum_k sum_j W_conv[k][j] * dconv[k][tau' - j + Ks] for the tile's frames:
-            // item = (tap range, kernel, group of 4 outputs) with a sliding register window; partial sums meet in LDS
+            // item = (tap range, kernel, group of 4 outputs); four taps per round from three 16-byte LDS reads
             constexpr int ngrp = TE / 4;
             const int nitem = Kn * ngrp;
             const int parts = max(1, min(4, nct / nitem));
-            const int tp = (taps + parts - 1) / parts;
+            const int gpp = (WT / 4 + parts - 1) / parts;                 // tap groups per part
             for (int it = tid; it < parts * nitem; it += nct) {
                 const int pz = it / nitem, o = it - pz * nitem, k = o / ngrp, ig = o - k * ngrp;
-                const int j0 = pz * tp, j1 = min(taps, j0 + tp);
-                const float* wk = s_wc + k * taps;
-                const float* dc = s_dcp + k * DW + tau0 + 4 * ig + 2 * Ks;      // dc[i - jj] for output i of the group
+                const int g0 = pz * gpp, g1 = min(WT / 4, g0 + gpp);
+                const float* wk = s_wc + k * WT;
+                const float* q0 = s_dcp + k * DW + PADL + Ks + tau0 + 4 * ig;       // q0[i - jj] = dconv[k][tau' - jj + Ks], 16-byte aligned
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                float p1 = 0.f, p2 = 0.f, p3 = 0.f;
-                if (j0 < j1) { p1 = dc[1 - j0]; p2 = dc[2 - j0]; p3 = dc[3 - j0]; }
-                for (int jj = j0; jj < j1; ++jj) {
-                    const float wv = wk[jj], p0 = dc[-jj];
-                    a0 += wv * p0; a1 += wv * p1; a2 += wv * p2; a3 += wv * p3;
-                    p3 = p2; p2 = p1; p1 = p0;
+                for (int g = g0; g < g1; ++g) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wk + 4 * g);
+                    const float4 lo = *reinterpret_cast<const float4*>(q0 - 4 * g - 4);   // q[-4..-1]
+                    const float4 hi = *reinterpret_cast<const float4*>(q0 - 4 * g);       // q[0..3]
+                    a0 += w4.x * hi.x + w4.y * lo.w + w4.z * lo.z + w4.w * lo.y;
+                    a1 += w4.x * hi.y + w4.y * hi.x + w4.z * lo.w + w4.w * lo.z;
+                    a2 += w4.x * hi.z + w4.y * hi.y + w4.z * hi.x + w4.w * lo.w;
+                    a3 += w4.x * hi.w + w4.y * hi.z + w4.z * hi.y + w4.w * hi.x;
                 }
-                float* o4 = s_pt + (long)(pz * Kn + k) * TE + 4 * ig;
-                o4[0] = a0; o4[1] = a1; o4[2] = a2; o4[3] = a3;
+                *reinterpret_cast<float4*>(s_pt + (long)(pz * Kn + k) * TE + 4 * ig) = make_float4(a0, a1, a2, a3);
             }
             cbar(&s_bar, gen, ncw);                                     // s_dq, s_pt complete
             // query part of dh_{t-1}: sum_a dq[a] * W_q[a][unit] for the own units (weights in registers)
@@ -1114,7 +1125,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                     float acc = 0.f;
 #pragma unroll
                     for (int k5 = 0; k5 < 5; ++k5) acc += dqr[k5] * wq[i][k5];
-                    acc = wave_sum(acc);
+                    acc = wave_sum_dpp(acc);
                     const int ul = wave + ncw * i;
                     if (lane == 0 && ul < p.UPW) s_hq[ul] = (u_base + ul < Dd) ? acc : 0.f;
                 }
@@ -1122,20 +1133,25 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             cbar(&s_bar, gen, ncw);                                     // s_hq complete
             // N record {datt_next tile | dh_q slice}
             if (tid < p.NG2) {
-                const int nitem2 = Kn * (TE / 4);
-                const int parts2 = max(1, min(4, nct / nitem2));
                 float v[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * tid + h;
                     float sv = 0.f;
-                    if (i < TE) { for (int r = 0; r < parts2 * Kn; ++r) sv += s_pt[(long)r * TE + i]; }
+                    if (i < TE) { for (int r = 0; r < parts * Kn; ++r) sv += s_pt[(long)r * TE + i]; }
                     else if (i - TE < p.UPW) sv = s_hq[i - TE];
                     v[h] = sv;
                 }
                 u64* dst = out + offN + (long)j * p.NG2 + tid;
                 if (local) publish<true>(dst, pack2(v[0], v[1], want)); else publish<false>(dst, pack2(v[0], v[1], want));
             }
+            // operands of the next step's cell backward (they arrive while the N records are gathered)
+            const long r1 = row - 1;
+            const float* g = p.s.gates + r1 * 4 * Dd + uc;
+            pgi = g[0]; pgf = g[Dd]; pgg = g[2 * Dd]; pgo = g[3 * Dd];
+            pct = p.s.cs[r1 * Dd + uc];
+            pcp = (t > 1) ? p.s.cs[(r1 - 1) * Dd + uc] : 0.f;
+            pdh = p.dhs[r1 * Dd + uc];
         }
         DP_MARK(11)
         __syncthreads();                                                // H4: s_nrec holds the N records for the next step
@@ -1167,7 +1183,7 @@ PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
     if (!TE) return pl;
     pl.TE = TE; pl.NT = cdiv(d.Tp, TE);
     pl.UPW = cdiv(d.Dd, pl.NT); pl.CPW = cdiv(d.E, pl.NT);
-    if (pl.UPW > UQW * ncw || pl.UPW + pl.CPW > RPWB * (ncw + NPB) || d.Kn * TE > 2 * nct || (TE + pl.UPW + 1) / 2 + 1 > nct) return pl;
+    if (pl.UPW > UQW * ncw || pl.UPW + pl.CPW > RCB * ncw + RPB * NPB || d.Kn * TE > 2 * nct || (TE + pl.UPW + 1) / 2 + 1 > nct) return pl;
     pl.R4 = (4 * d.Dd + 7) & ~7;
     auto even = [](int x) { return (x + 1) & ~1; };
     pl.CG2 = even((pl.CPW + pl.UPW + 1) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even((TE + pl.UPW + 1) / 2);

@@ -63,6 +63,30 @@ inline size_t align_up256(size_t x) { return (x + 255) & ~(size_t)255; }
 __device__ __forceinline__ float bf2f_(unsigned short x) { return __uint_as_float((unsigned)x << 16); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
+// wave-wide sum on the DPP path (quad swaps, mirrors, row broadcasts: 6 VALU steps, no LDS permutes); uniform result
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define DPB_STEP(CTRL, RMASK) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false));
+    DPB_STEP(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    DPB_STEP(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    DPB_STEP(0x141, 0xf)     // row_half_mirror
+    DPB_STEP(0x140, 0xf)     // row_mirror
+    DPB_STEP(0x142, 0xa)     // row_bcast15 -> rows 1, 3
+    DPB_STEP(0x143, 0xc)     // row_bcast31 -> rows 2, 3
+#undef DPB_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+#define DPB_STEP(CTRL, RMASK) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false)));
+    DPB_STEP(0xB1, 0xf)
+    DPB_STEP(0x4E, 0xf)
+    DPB_STEP(0x141, 0xf)
+    DPB_STEP(0x140, 0xf)
+    DPB_STEP(0x142, 0xa)
+    DPB_STEP(0x143, 0xc)
+#undef DPB_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 struct PD {
     asr_dec_dims_t d;
     asr_dec_weights_t w;
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                     acc0 += w0[k] * hv; acc1 += w1[k] * hv;
                 }
                 for (int kk = lane + 320; kk < Dd; kk += 64) { const float hv = s_x[E + kk]; acc0 += p.w.Wq[(long)a0 * Dd + kk] * hv; acc1 += p.w.Wq[(long)a1 * Dd + kk] * hv; }
-                acc0 = wave_sum(acc0); acc1 = wave_sum(acc1);
+                acc0 = wave_sum_dpp(acc0); acc1 = wave_sum_dpp(acc1);
             }
             if (lane == 0) {
                 const float q0 = tanhf(acc0 + p.w.bq[a0]), q1 = tanhf(acc1 + p.w.bq[a1]);
@@ -345,7 +369,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const float sv = wave_sum(e[i]);
+                const float sv = wave_sum_dpp(e[i]);
                 const int f = wave * TPW + i;
                 if (lane == 0) s_e[f] = (tau0 + f < len) ? (sv + bg) / d.temperature : NEG_BIG;
             }
@@ -356,9 +380,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
         // ---- local softmax statistics (every wave for itself) and the tile's partial context
         {
             const float ev = (lane < TE) ? s_e[lane] : NEG_BIG;
-            const float m = wave_max(ev);
+            const float m = wave_max_dpp(ev);
             const float wv = (ev > 0.5f * NEG_BIG) ? __expf(ev - m) : 0.f;
-            const float ssum = wave_sum(wv);
+            const float ssum = wave_sum_dpp(wv);
             // thread c2: context columns 2*c2, 2*c2+1
             const int c2 = tid;
             float x0 = 0.f, x1 = 0.f;
@@ -396,9 +420,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
         {
             float mi = NEG_BIG, si = 0.f;
             if (lane < NT) { mi = s_stage[lane * SG2f + TE]; si = s_stage[lane * SG2f + TE + 1]; }
-            const float M = wave_max(mi);
+            const float M = wave_max_dpp(mi);
             const float wi = (lane < NT) ? si * __expf(mi - M) : 0.f;
-            const float S = fmaxf(wave_sum(wi), 1e-30f);
+            const float S = fmaxf(wave_sum_dpp(wi), 1e-30f);
             const float invS = 1.f / S;
             if (lane < 32) s_scale[wave][lane] = (lane < NT) ? __expf(mi - M) * invS : 0.f;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                 }
 #pragma unroll
                 for (int rr = 0; rr < RB; ++rr) {
-                    const float sv = wave_sum(part[rr]);
+                    const float sv = wave_sum_dpp(part[rr]);
                     if (lane == bt * RB + rr) mine = sv;
                 }
             }
@@ -617,19 +641,6 @@ __device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_, a), __builtin_bit_cast(bf16x2_, b), c, false);
 }
 
-// wave-wide sum on the DPP path (quad swaps, mirrors, row broadcasts: 6 VALU steps, no LDS permutes); uniform result
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-#define DPB_STEP(CTRL, RMASK) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false));
-    DPB_STEP(0xB1, 0xf)      // quad_perm [1,0,3,2]
-    DPB_STEP(0x4E, 0xf)      // quad_perm [2,3,0,1]
-    DPB_STEP(0x141, 0xf)     // row_half_mirror
-    DPB_STEP(0x140, 0xf)     // row_mirror
-    DPB_STEP(0x142, 0xa)     // row_bcast15 -> rows 1, 3
-    DPB_STEP(0x143, 0xc)     // row_bcast31 -> rows 2, 3
-#undef DPB_STEP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
 struct PB {
     asr_dec_dims_t d;
     asr_dec_weights_t w;
@@ -654,19 +665,22 @@ struct PB {
 };
 
 // LDS carve of dec_bwd_persist, shared by the kernel and the host plan (float offsets follow the bf16 arrays).
-struct BCarve { int AP, DW, PADL, WT, key, dl, wp16, dg16, shorts; int wc, crec, qst, nrec, dcp, cv, de, out, hq, pt, dcx, dq, floats; };
+struct BCarve { int AP, DW, PADL, WT, AQ, key, dl, wp16, dg16, wq16, shorts; int wc, crec, qst, nrec, dcp, cv, de, out, hq, pt, dcx, dq, floats; };
 __host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn, int Ks, int NT, int UPW, int CG2, int QG2, int NG2) {
     BCarve c;
     int ap8 = 4 * ((A + 31) / 32); if ((ap8 & 1) == 0) ++ap8;
     c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: >= 32*ceil(A/32), odd in 16-byte units
     c.PADL = Ks + 8 + ((4 - ((2 * Ks) & 3)) & 3);       // left zero pad of a dconv row: PADL + Ks is a multiple of 4
-    c.DW = (c.PADL + NT * TE + Ks + 8 + 3) & ~3;        // zero-padded dconv row
+    c.DW = (c.PADL + NT * TE + Ks + 8 + 3) & ~3;        // zero-padded dconv row,
+    if (((c.DW >> 2) & 1) == 0) c.DW += 4;              //   an odd number of 16-byte units (bank spread across the Kn rows)
     c.WT = (2 * Ks + 1 + 3) & ~3;                       // zero-padded filter row
     int o = 0;
     c.key = o; o += (TE * A + 7) & ~7;
     c.dl = o; o += TE * c.AP;
     c.wp16 = o; o += 16 * c.AP;
     c.dg16 = o; o += 64 * KCHB * 4;
+    c.AQ = 64 * ((A + 63) / 64);                        // row of the resident W_q^T slice
+    c.wq16 = o; o += ((UPW + 1) & ~1) * c.AQ;
     c.shorts = o;
     o = 0;
     c.wc = o; o += Kn * c.WT;
@@ -760,7 +774,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     const int len = min((int)p.enc_len[b], Tp);
     const int tmax = max(len - 1, 0);
     const BCarve cv_ = bwd_carve(TE, KP, A, E, Kn, Ks, NT, p.UPW, p.CG2, p.QG2, p.NG2);
-    const int AP = cv_.AP, DW = cv_.DW, PADL = cv_.PADL, WT = cv_.WT;
+    const int AP = cv_.AP, DW = cv_.DW, PADL = cv_.PADL, WT = cv_.WT, AQ = cv_.AQ;
     const int TW = NT * TE;                                             // padded attention row
     const int CG2f = 2 * p.CG2, NG2f = 2 * p.NG2, QG2f = 2 * p.QG2;
     // ---- LDS carve
@@ -769,6 +783,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     unsigned short* s_dl = s_sh + cv_.dl;                                                // [TE][AP] bf16  d loc pre-activation
     unsigned short* s_wp16 = s_sh + cv_.wp16;                                            // [16][AP] bf16  W_proj^T, zero padded
     unsigned short* s_dg16 = s_sh + cv_.dg16;                                            // [1280] bf16 dgates of the utterance
+    unsigned short* s_wq16 = s_sh + cv_.wq16;                                            // [UPW][AQ] bf16 rows of W_q^T of the own units
     float* s_f = reinterpret_cast<float*>(s_sh + cv_.shorts);
     float* s_wc = s_f + cv_.wc;                                                          // [Kn*taps]
     float* s_crec = s_f + cv_.crec;                                                      // [NT][CG2*2] records {dctx slice, dh_rec slice}
@@ -812,6 +827,10 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     for (int i = tid; i < TE * AP; i += blockDim.x) s_dl[i] = 0;
     for (int i = tid; i < TE * KP; i += blockDim.x) s_cv[i] = 0.f;
     const int u_base = j * p.UPW, c_base = j * p.CPW;
+    for (int i = tid; i < p.UPW * AQ; i += blockDim.x) {
+        const int ul = i / AQ, aa = i - ul * AQ;
+        s_wq16[i] = (aa < A && u_base + ul < Dd) ? f2bf_bits(p.wqT[(long)(u_base + ul) * A + aa]) : (unsigned short)0;
+    }
     const int nout = p.CPW + p.UPW;
     // rows of the transposed cell weights are register-resident: compute wave w has outputs w + ncw*o (o < RCB), polling
     // wave pw has RCB*ncw + pw + NPB*o (o < RPB)
@@ -820,6 +839,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     if (wave >= ncw) {
         // =========================== polling role ===========================
         const int gt = tid - nct, np = 64 * NPB;
+        const int vp0 = max(0, (tau0 - Ks) / TE), vp1 = min(NT - 1, (tau0 + TE - 1 + Ks) / TE);   // tiles whose dconv this tile's datt_next reads
         const int obase = RCB * ncw + (wave - ncw);
         uint2 wreg[RPB][KCHB];
         DPB_WLOAD(RPB, obase, NPB)
@@ -833,24 +853,35 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             poll_copy<4>(base + offC, NT * p.CG2 / 2, s_crec, gt, np, want, p.status);
             __syncthreads();                                            // H2
             for (int z = 0; z < p.poll_delay; ++z) __builtin_amdgcn_s_sleep(127);
-            poll_copy<8>(base + offQ, NT * p.QG2 / 2, s_qst, gt, np, want, p.status);
-            {   // dconv tiles go straight into the zero-padded per-kernel rows: s_dcp[k][Ks + prod*TE + f]
-                const int n16 = NT * p.VG2 / 2;
-                for (int i0 = gt; i0 < n16; i0 += 8 * np) {
-                    u64 lo[8], hi[8];
+            {   // Q records of all tiles (flat copy) and the dconv tiles V of the tiles within reach of the location filter
+                // (they go straight into the zero-padded per-kernel rows s_dcp[k][PADL + prod*TE + f]), as ONE polling sweep
+                const int nq = NT * p.QG2 / 2, nv = (vp1 - vp0 + 1) * (p.VG2 / 2);
+                const u64* vbase = base + offV + (long)vp0 * p.VG2;
+                for (int i0 = gt; i0 < nq + nv; i0 += 10 * np) {
+                    u64 lo[10], hi[10];
+                    const u64* addr[10];
                     int cnt = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) if (i0 + k * np < n16) cnt = k + 1;
-                    gather16<8>(base + offV + 2 * i0, 2 * np, cnt, PAIR_MASK, want, lo, hi, p.status);
+                    for (int k = 0; k < 10; ++k) {
+                        const int idx = i0 + k * np;
+                        if (idx < nq + nv) cnt = k + 1;
+                        addr[k] = (idx < nq) ? base + offQ + 2 * (long)idx : vbase + 2 * (long)min(idx - nq, nv - 1);
+                    }
+                    gather16v<10>(addr, cnt, PAIR_MASK, want, lo, hi, p.status);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    for (int k = 0; k < 10; ++k)
                         if (k < cnt) {
-                            const int g0 = 2 * (i0 + k * np), prod = g0 / p.VG2, r0 = 2 * (g0 - prod * p.VG2);
+                            const int idx = i0 + k * np;
                             const float v[4] = {lo_f(lo[k]), hi_f(lo[k]), lo_f(hi[k]), hi_f(hi[k])};
+                            if (idx < nq) {
+                                *reinterpret_cast<float4*>(s_qst + 4 * (long)idx) = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
+                                const int g0 = vp0 * p.VG2 + 2 * (idx - nq), prod = g0 / p.VG2, r0 = 2 * (g0 - prod * p.VG2);
 #pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4) {
-                                const int r = r0 + q4;
-                                if (r < Kn * TE) { const int kk = r / TE, f = r - kk * TE; s_dcp[kk * DW + PADL + prod * TE + f] = v[q4]; }
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    const int r = r0 + q4;
+                                    if (r < Kn * TE) { const int kk = r / TE, f = r - kk * TE; s_dcp[kk * DW + PADL + prod * TE + f] = v[q4]; }
+                                }
                             }
                         }
                 }
@@ -877,13 +908,6 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
 #pragma unroll
     for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < Kn) ? p.w.Wproj[ac * Kn + k] : 0.f; dwp[k] = 0.f; }
     const float wga = p.w.wg[ac];
-    float wq[UQW][5];                                                   // W_q^T rows of units u_base + wave + ncw*i, columns lane + 64k
-#pragma unroll
-    for (int i = 0; i < UQW; ++i) {
-        const int unit = min(u_base + min(wave + ncw * i, p.UPW - 1), Dd - 1);
-#pragma unroll
-        for (int k5 = 0; k5 < 5; ++k5) wq[i][k5] = (lane + 64 * k5 < A) ? p.wqT[(long)unit * A + min(lane + 64 * k5, A - 1)] : 0.f;
-    }
     float dwg = 0.f, dbg = 0.f, dc_carry = 0.f;
     // operands of the cell backward of step L-1 (later steps: requested one step ahead)
     float pgi, pgf, pgg, pgo, pct, pcp, pdh;
@@ -1090,6 +1114,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             const int asl = (A + NT - 1) / NT;
             if (aok && a >= j * asl && a < (j + 1) * asl) p.dq[row * A + a] = dqv;     // each workgroup saves a slice
         }
+        DP_MARK(13)
         if (t > 0) {
             // datt_next[tau'] = sum_k sum_j W_conv[k][j] * dconv[k][tau' - j + Ks] for the tile's frames:
             // item = (tap range, kernel, group of 4 outputs); four taps per round from three 16-byte LDS reads
@@ -1100,13 +1125,15 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             for (int it = tid; it < parts * nitem; it += nct) {
                 const int pz = it / nitem, o = it - pz * nitem, k = o / ngrp, ig = o - k * ngrp;
                 const int g0 = pz * gpp, g1 = min(WT / 4, g0 + gpp);
-                const float* wk = s_wc + k * WT;
-                const float* q0 = s_dcp + k * DW + PADL + Ks + tau0 + 4 * ig;       // q0[i - jj] = dconv[k][tau' - jj + Ks], 16-byte aligned
+                // 16-byte units throughout (s_wc rows, the dconv rows and PADL + Ks + tau0 are multiples of 4 floats)
+                const float4* wk4 = reinterpret_cast<const float4*>(s_wc) + (k * WT) / 4;
+                const float4* q4 = reinterpret_cast<const float4*>(s_dcp) + (k * DW + PADL + Ks + tau0) / 4 + ig;   // q4[0] = q[0..3]
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 3
                 for (int g = g0; g < g1; ++g) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(wk + 4 * g);
-                    const float4 lo = *reinterpret_cast<const float4*>(q0 - 4 * g - 4);   // q[-4..-1]
-                    const float4 hi = *reinterpret_cast<const float4*>(q0 - 4 * g);       // q[0..3]
+                    const float4 w4 = wk4[g];
+                    const float4 lo = q4[-g - 1];                       // q[-4..-1] of this tap group
+                    const float4 hi = q4[-g];                           // q[0..3]
                     a0 += w4.x * hi.x + w4.y * lo.w + w4.z * lo.z + w4.w * lo.y;
                     a1 += w4.x * hi.y + w4.y * hi.x + w4.z * lo.w + w4.w * lo.z;
                     a2 += w4.x * hi.z + w4.y * hi.y + w4.z * hi.x + w4.w * lo.w;
@@ -1114,33 +1141,39 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                 }
                 *reinterpret_cast<float4*>(s_pt + (long)(pz * Kn + k) * TE + 4 * ig) = make_float4(a0, a1, a2, a3);
             }
+            DP_MARK(14)
             cbar(&s_bar, gen, ncw);                                     // s_dq, s_pt complete
-            // query part of dh_{t-1}: sum_a dq[a] * W_q[a][unit] for the own units (weights in registers)
+            // query part of dh_{t-1}: sum_a dq[a] * W_q[a][unit] for the own units (bf16 rows in LDS)
             {
                 float dqr[5];
 #pragma unroll
                 for (int k5 = 0; k5 < 5; ++k5) dqr[k5] = (lane + 64 * k5 < A) ? s_dq[min(lane + 64 * k5, A - 1)] : 0.f;
-#pragma unroll
-                for (int i = 0; i < UQW; ++i) {
+                for (int ul = wave; ul < p.UPW; ul += ncw) {
+                    const unsigned short* wr = s_wq16 + ul * AQ + lane;
                     float acc = 0.f;
 #pragma unroll
-                    for (int k5 = 0; k5 < 5; ++k5) acc += dqr[k5] * wq[i][k5];
+                    for (int k5 = 0; k5 < 5; ++k5) if (64 * k5 < AQ) acc += dqr[k5] * bf2f_(wr[64 * k5]);
                     acc = wave_sum_dpp(acc);
-                    const int ul = wave + ncw * i;
-                    if (lane == 0 && ul < p.UPW) s_hq[ul] = (u_base + ul < Dd) ? acc : 0.f;
+                    if (lane == 0) s_hq[ul] = acc;
                 }
             }
-            cbar(&s_bar, gen, ncw);                                     // s_hq complete
+            // datt_next of the tile: the tap-range partial sums, 8 threads per frame (s_de is free after the sweep)
+            {
+                const int i = tid >> 3, sub = tid & 7;
+                float sv = 0.f;
+                if (i < TE) for (int r = sub; r < parts * Kn; r += 8) sv += s_pt[(long)r * TE + i];
+                sv += __shfl_xor(sv, 4); sv += __shfl_xor(sv, 2); sv += __shfl_xor(sv, 1);
+                if (i < TE && sub == 0) s_de[i] = sv;
+            }
+            DP_MARK(15)
+            cbar(&s_bar, gen, ncw);                                     // s_hq, datt_next complete
             // N record {datt_next tile | dh_q slice}
             if (tid < p.NG2) {
                 float v[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * tid + h;
-                    float sv = 0.f;
-                    if (i < TE) { for (int r = 0; r < parts * Kn; ++r) sv += s_pt[(long)r * TE + i]; }
-                    else if (i - TE < p.UPW) sv = s_hq[i - TE];
-                    v[h] = sv;
+                    v[h] = (i < TE) ? s_de[i] : ((i - TE < p.UPW) ? s_hq[i - TE] : 0.f);
                 }
                 u64* dst = out + offN + (long)j * p.NG2 + tid;
                 if (local) publish<true>(dst, pack2(v[0], v[1], want)); else publish<false>(dst, pack2(v[0], v[1], want));
@@ -1183,13 +1216,13 @@ PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
     if (!TE) return pl;
     pl.TE = TE; pl.NT = cdiv(d.Tp, TE);
     pl.UPW = cdiv(d.Dd, pl.NT); pl.CPW = cdiv(d.E, pl.NT);
-    if (pl.UPW > UQW * ncw || pl.UPW + pl.CPW > RCB * ncw + RPB * NPB || d.Kn * TE > 2 * nct || (TE + pl.UPW + 1) / 2 + 1 > nct) return pl;
+    if (pl.UPW > 64 || pl.UPW + pl.CPW > RCB * ncw + RPB * NPB || d.Kn * TE > 2 * nct || (TE + pl.UPW + 1) / 2 + 1 > nct) return pl;
     pl.R4 = (4 * d.Dd + 7) & ~7;
     auto even = [](int x) { return (x + 1) & ~1; };
     pl.CG2 = even((pl.CPW + pl.UPW + 1) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even((TE + pl.UPW + 1) / 2);
     const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.CG2, pl.QG2, pl.NG2);
     pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
-    if (pl.lds > 150 * 1024) return pl;
+    if (pl.lds > 160 * 1024 - 4096) return pl;
     pl.status_bytes = 4096;
     pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.CG2 + pl.QG2 + pl.VG2 + pl.NG2) * sizeof(u64));
     pl.w16_bytes = align_up256((size_t)(d.Dd + d.E + d.Dd) * pl.R4 * 2);

@@ -82,4 +82,37 @@ __device__ __forceinline__ int gather16(const u64* base, long stride, int n, u64
 }
 
 
+// Same polling sweep with an explicit address per entry (entries >= n re-read entry 0 and are not checked).
+template <int CH>
+__device__ __forceinline__ int gather16v(const u64* const (&addr)[CH], int n, u64 mask, u64 want, u64 (&lo)[CH], u64 (&hi)[CH],
+                                         unsigned* abort_flag) {
+    int spins = 0;
+    while (true) {
+        u32x4 v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const u64* a = addr[i < n ? i : 0];
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            lo[i] = (u64)v[i][0] | ((u64)v[i][1] << 32);
+            hi[i] = (u64)v[i][2] | ((u64)v[i][3] << 32);
+            ok = ok && ((i >= n) || (((lo[i] & mask) == want) && ((hi[i] & mask) == want)));
+        }
+        if (ok) return spins;
+        ++spins;
+        if ((spins & 63) == 0) {
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return spins;
+            if (spins > SPIN_LIMIT2) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return spins;
+            }
+        }
+    }
+}
+
+
 }  // namespace

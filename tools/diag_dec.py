@@ -45,7 +45,8 @@ for it in range(2):
 from src import functions as F2
 NB = ['wait H4 .. S1 start', 'S1 cell bwd (all units)', 'Ba barrier', 'P1 transposed weights (registers) . dgates', 'Bb barrier',
       'C publish + operand requests', 'wait C (H2)', 'P2 dattn + dot + de', 'P3 sweep + Q publish', 'P4 dconv (MFMA) + V publish',
-      'wait Q,V (H3)', 'P5 dq, datt_next, query part, N publish', 'wait N (H4)']
+      'wait Q,V (H3)', 'P5d barrier, N publish, operand requests', 'wait N (H4)', 'P5a dq sum', 'P5b transposed conv partials',
+      'P5c barrier, query part, tile sums']
 model.zero_grad()
 enc2 = enc.clone().requires_grad_(True)
 logits, _, _ = F2.AttDecoderFn.apply(model._anchor, enc2, enc_len, teacher, L, model, H.BF16)

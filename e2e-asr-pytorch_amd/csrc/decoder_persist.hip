@@ -665,11 +665,11 @@ struct PB {
 };
 
 // LDS carve of dec_bwd_persist, shared by the kernel and the host plan (float offsets follow the bf16 arrays).
-struct BCarve { int AP, DW, PADL, WT, AQ, key, dl, wp16, dg16, wq16, shorts; int wc, crec, qst, nrec, dcp, cv, de, out, hq, pt, dcx, dq, floats; };
+struct BCarve { int AP, DW, PADL, WT, AQ, key, dl, wp16, dg16, wq16, shorts; int wc, crec, qst, nrec, dcp, cv, de, out, hq, pt, dcx, dq, dqx, floats; };
 __host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn, int Ks, int NT, int UPW, int CG2, int QG2, int NG2) {
     BCarve c;
-    int ap8 = 4 * ((A + 31) / 32); if ((ap8 & 1) == 0) ++ap8;
-    c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: >= 32*ceil(A/32), odd in 16-byte units
+    int ap8 = 8 * ((A + 63) / 64); if ((ap8 & 1) == 0) ++ap8;
+    c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: >= 64*ceil(A/64), odd in 16-byte units
     c.PADL = Ks + 8 + ((4 - ((2 * Ks) & 3)) & 3);       // left zero pad of a dconv row: PADL + Ks is a multiple of 4
     c.DW = (c.PADL + NT * TE + Ks + 8 + 3) & ~3;        // zero-padded dconv row,
     if (((c.DW >> 2) & 1) == 0) c.DW += 4;              //   an odd number of 16-byte units (bank spread across the Kn rows)
@@ -695,6 +695,7 @@ __host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn
     c.pt = o; o += 4 * Kn * TE;
     c.dcx = o; o += (E + 3) & ~3;
     c.dq = o; o += (A + 3) & ~3;
+    c.dqx = o; o += NPB * 64;
     c.floats = o;
     return c;
 }
@@ -754,6 +755,47 @@ __device__ __forceinline__ void poll_copy(const u64* src, int n16, float* dst, i
         }                                                                                                              \
     }
 
+#ifdef ASR_DBG_NOATOM
+#define DPB_ATOM(P, V) { if ((V) == 12345.678f) *(P) = 0.f; }
+#else
+#define DPB_ATOM(P, V) atomicAdd(P, V)
+#endif
+// energy backward of frames [F0, F1) (an even count) of the tile for attention column COL (one lane): recomputes
+// loc = tanh(W_proj conv) and u = tanh(key + q + loc); accumulates d w_g, d W_proj, the query gradient; dkey by fire-and-forget
+// atomics; dl -> s_dl (bf16).  Two frames per round as straight-line code (no lane-dependent branches: masked frames add 0 to
+// a clamped row, columns >= A land in the pad columns of s_dl) so that the two dependency chains interleave.
+#define DPB_SWEEP(F0, F1, COL, LCOL, WP, DWP, DWG, DQA, QA, WGA)                                                       \
+    {                                                                                                                  \
+        float* dkp_ = p.dkey + (long)b * Tp * A + (COL);                                                               \
+        _Pragma("unroll 1") for (int f = (F0); f < (F1); f += 2) {                                                     \
+            float cva[KP], cvb[KP];                                                                                    \
+            _Pragma("unroll") for (int k4 = 0; k4 < KP; k4 += 4) {                                                     \
+                const float4 c4 = *reinterpret_cast<const float4*>(s_cv + f * KP + k4);                                \
+                const float4 e4 = *reinterpret_cast<const float4*>(s_cv + (f + 1) * KP + k4);                          \
+                cva[k4] = c4.x; cva[k4 + 1] = c4.y; cva[k4 + 2] = c4.z; cva[k4 + 3] = c4.w;                            \
+                cvb[k4] = e4.x; cvb[k4 + 1] = e4.y; cvb[k4 + 2] = e4.z; cvb[k4 + 3] = e4.w;                            \
+            }                                                                                                          \
+            const float ka = bf2f_(s_key[f * A + (COL)]), kb = bf2f_(s_key[(f + 1) * A + (COL)]);                      \
+            const float dea = s_de[f], deb = s_de[f + 1];                                                              \
+            float la0 = 0.f, la1 = 0.f, lb0 = 0.f, lb1 = 0.f;                                                          \
+            _Pragma("unroll") for (int k = 0; k < KNMAX; k += 2) {                                                     \
+                la0 += (WP)[k] * cva[k]; lb0 += (WP)[k] * cvb[k];                                                      \
+                if (k + 1 < KNMAX) { la1 += (WP)[k + 1] * cva[k + 1]; lb1 += (WP)[k + 1] * cvb[k + 1]; }               \
+            }                                                                                                          \
+            const float loca = tanh_f(la0 + la1), locb = tanh_f(lb0 + lb1);                                            \
+            const float ua = tanh_f(ka + (QA) + loca), ub = tanh_f(kb + (QA) + locb);                                  \
+            const float dua = dea * (WGA) * (1.f - ua * ua), dub = deb * (WGA) * (1.f - ub * ub);                      \
+            const float dla = dua * (1.f - loca * loca), dlb = dub * (1.f - locb * locb);                              \
+            (DWG) += dea * ua + deb * ub;                                                                              \
+            (DQA) += dua + dub;                                                                                        \
+            _Pragma("unroll") for (int k = 0; k < KNMAX; ++k) (DWP)[k] += dla * cva[k] + dlb * cvb[k];                 \
+            DPB_ATOM(dkp_ + (long)min(tau0 + f, Tp - 1) * A, dua);                                                     \
+            DPB_ATOM(dkp_ + (long)min(tau0 + f + 1, Tp - 1) * A, dub);                                                 \
+            s_dl[f * AP + (LCOL)] = f2bf_bits(dla);                                                                    \
+            s_dl[(f + 1) * AP + (LCOL)] = f2bf_bits(dlb);                                                              \
+        }                                                                                                              \
+    }
+
 template <int KNMAX, int TE>
 __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -797,6 +839,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     float* s_pt = s_f + cv_.pt;                                                          // [4*Kn*TE] partial sums of datt_next (tap ranges)
     float* s_dcx = s_f + cv_.dcx;                                                        // [E] dctx, contiguous
     float* s_dq = s_f + cv_.dq;                                                          // [A] dq of the utterance
+    float* s_dqx = s_f + cv_.dqx;                                                        // [NPB][64] query-gradient partials of the tail columns
     const long region = (long)NT * (p.CG2 + p.QG2 + p.VG2 + p.NG2);
     auto xb = [&](int parity) { return p.xbuf + ((long)parity * d.B + b) * region; };
     const long offC = 0, offQ = offC + (long)NT * p.CG2, offV = offQ + (long)NT * p.QG2, offN = offV + (long)NT * p.VG2;
@@ -832,6 +875,9 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         s_wq16[i] = (aa < A && u_base + ul < Dd) ? f2bf_bits(p.wqT[(long)(u_base + ul) * A + aa]) : (unsigned short)0;
     }
     const int nout = p.CPW + p.UPW;
+    // The sweep is VALU-bound and ncw compute waves share 4 SIMDs, so the columns of the LAST compute wave ("tail", a >= 64*(ncw-1))
+    // are swept by four waves - that wave and the three polling waves - a quarter of the tile's frames each.
+    const int xa0 = 64 * (ncw - 1), fq = (TE + 3) / 4;
     // rows of the transposed cell weights are register-resident: compute wave w has outputs w + ncw*o (o < RCB), polling
     // wave pw has RCB*ncw + pw + NPB*o (o < RPB)
     __syncthreads();
@@ -843,6 +889,16 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         const int obase = RCB * ncw + (wave - ncw);
         uint2 wreg[RPB][KCHB];
         DPB_WLOAD(RPB, obase, NPB)
+        const int pw = wave - ncw;
+        const int ax = xa0 + lane;                                      // tail column of this lane
+        const bool axok = ax < A;
+        const int axc = axok ? ax : A - 1;
+        const int xf0 = min(TE, fq * (pw + 1)), xf1 = min(TE, fq * (pw + 2));
+        float wpx[KNMAX], dwpx[KNMAX];
+#pragma unroll
+        for (int k = 0; k < KNMAX; ++k) { wpx[k] = (k < Kn) ? p.w.Wproj[axc * Kn + k] : 0.f; dwpx[k] = 0.f; }
+        const float wgax = axok ? p.w.wg[axc] : 0.f;              // 0: the pad lanes contribute nothing
+        float dwgx = 0.f;
         for (int t = L - 1; t >= 0; --t) {
             const int s = L - 1 - t;                                     // step counter of this launch (tags, parity)
             const u64 want = pair_want(seq_of(s), p.epoch);
@@ -851,7 +907,15 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             DPB_P1(RPB, obase, NPB)
             __syncthreads();                                            // Bb: s_out complete
             poll_copy<4>(base + offC, NT * p.CG2 / 2, s_crec, gt, np, want, p.status);
+            const float qax = p.s.q[((long)b * L + t) * A + axc];
             __syncthreads();                                            // H2
+            __syncthreads();                                            // X1: s_de, s_cv complete
+            {
+                float dqx = 0.f;
+                if (tau0 < len) DPB_SWEEP(xf0, xf1, axc, ax, wpx, dwpx, dwgx, dqx, qax, wgax)
+                s_dqx[pw * 64 + lane] = dqx;
+            }
+            __syncthreads();                                            // X2: s_dl, s_dqx complete
             for (int z = 0; z < p.poll_delay; ++z) __builtin_amdgcn_s_sleep(127);
             {   // Q records of all tiles (flat copy) and the dconv tiles V of the tiles within reach of the location filter
                 // (they go straight into the zero-padded per-kernel rows s_dcp[k][PADL + prod*TE + f]), as ONE polling sweep
@@ -890,6 +954,14 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             if (t > 0) poll_copy<4>(base + offN, NT * p.NG2 / 2, s_nrec, gt, np, want, p.status);
             __syncthreads();                                            // H4
         }
+        // partial accumulators of the tail columns -> LDS (s_qst is free now); the tail compute wave adds them in fixed order
+        {
+            float* px = s_qst + (pw * 64 + lane) * (KNMAX + 1);
+            px[0] = dwgx;
+#pragma unroll
+            for (int k = 0; k < KNMAX; ++k) px[1 + k] = dwpx[k];
+        }
+        __syncthreads();                                                // F
         return;
     }
 
@@ -907,7 +979,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     float wp[KNMAX], dwp[KNMAX];
 #pragma unroll
     for (int k = 0; k < KNMAX; ++k) { wp[k] = (k < Kn) ? p.w.Wproj[ac * Kn + k] : 0.f; dwp[k] = 0.f; }
-    const float wga = p.w.wg[ac];
+    const float wga = aok ? p.w.wg[ac] : 0.f;                         // 0: the pad lanes contribute nothing
     float dwg = 0.f, dbg = 0.f, dc_carry = 0.f;
     // operands of the cell backward of step L-1 (later steps: requested one step ahead)
     float pgi, pgf, pgg, pgo, pct, pcp, pdh;
@@ -1027,42 +1099,21 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
             if (f2 < TE && part == 0) {
                 const int tau = tau0 + f2;
                 const float dat = v + ((s > 0) ? s_nrec[j * NG2f + f2] : 0.f);
-                s_de[f2] = (tau < len) ? attf * (dat - dot) / d.temperature : 0.f;
+                const float dev = (tau < len) ? attf * (dat - dot) / d.temperature : 0.f;
+                s_de[f2] = dev;
+                dbg += dev;                                             // d b_g: per-thread partial, added to the slot at the end
             }
         }
-        cbar(&s_bar, gen, ncw);
+        __syncthreads();                                                // X1: s_de, s_cv complete (the polling waves join the sweep)
         DP_MARK(7)
-        // ---- P3: energy backward sweep; thread a owns column a of all TE frames; dkey by fire-and-forget atomics
+        // ---- P3: energy backward sweep; thread a owns column a (all TE frames; a quarter of them for the tail columns)
         float dqa = 0.f;
         {
-            float* dkp = p.dkey + ((long)b * Tp + tau0) * A + ac;
-#pragma unroll 4
-            for (int f = 0; f < TE; ++f) {
-                float cvv[KP];
-#pragma unroll
-                for (int k4 = 0; k4 < KP; k4 += 4) {
-                    const float4 c4 = *reinterpret_cast<const float4*>(s_cv + f * KP + k4);
-                    cvv[k4] = c4.x; cvv[k4 + 1] = c4.y; cvv[k4 + 2] = c4.z; cvv[k4 + 3] = c4.w;
-                }
-                float lp = 0.f;
-#pragma unroll
-                for (int k = 0; k < KNMAX; ++k) lp += wp[k] * cvv[k];
-                const float loc = tanh_f(lp);
-                const float u = tanh_f(bf2f_(s_key[f * A + ac]) + qa + loc);
-                const float de = s_de[f];
-                const float du = de * wga * (1.f - u * u);
-                const float dl = du * (1.f - loc * loc);
-                dwg += de * u;
-                dqa += du;
-#pragma unroll
-                for (int k = 0; k < KNMAX; ++k) dwp[k] += dl * cvv[k];
-                if (aok && tau0 + f < len) atomicAdd(dkp + (long)f * A, du);
-                if (aok) s_dl[f * AP + a] = f2bf_bits(dl);
-            }
-            if (tid == 0) { for (int f = 0; f < TE; ++f) dbg += s_de[f]; }
+            const int f1 = (wave == ncw - 1) ? min(TE, fq) : TE;
+            if (tau0 < len) DPB_SWEEP(0, f1, ac, a, wp, dwp, dwg, dqa, qa, wga)
         }
         // query-gradient partial of this tile, already times (1 - q^2): pairs (a, a+1) by even lanes
-        {
+        if (wave < ncw - 1) {
             const float mine = aok ? dqa * (1.f - qa * qa) : 0.f;
             const float nb = __shfl_down(mine, 1);
             if ((lane & 1) == 0 && a < 2 * p.QG2) {
@@ -1070,7 +1121,18 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                 if (local) publish<true>(dst, pack2(mine, nb, want)); else publish<false>(dst, pack2(mine, nb, want));
             }
         }
-        cbar(&s_bar, gen, ncw);
+        __syncthreads();                                                // X2: s_dl complete, s_dqx holds the other quarters
+        if (wave == ncw - 1) {
+            float tot = dqa;
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) tot += s_dqx[q * 64 + lane];
+            const float mine = aok ? tot * (1.f - qa * qa) : 0.f;
+            const float nb = __shfl_down(mine, 1);
+            if ((lane & 1) == 0 && a < 2 * p.QG2) {
+                u64* dst = out + offQ + (long)j * p.QG2 + (a >> 1);
+                if (local) publish<true>(dst, pack2(mine, nb, want)); else publish<false>(dst, pack2(mine, nb, want));
+            }
+        }
         DP_MARK(8)
         // ---- P4: dconv (TE x Kn) = dl (TE x A) . W_proj (A x Kn) on the matrix cores, one 16-frame tile per wave
         if (wave < MT) {
@@ -1191,6 +1253,16 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         DP_MARK(12)
     }
     DP_DUMP
+    __syncthreads();                                                    // F: partial accumulators of the polling waves are in s_qst
+    if (wave == ncw - 1) {
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            const float* px = s_qst + (q * 64 + lane) * (KNMAX + 1);
+            dwg += px[0];
+#pragma unroll
+            for (int k = 0; k < KNMAX; ++k) dwp[k] += px[1 + k];
+        }
+    }
     // ---- results that were accumulated on chip: the slot of this workgroup
     if (aok) {
         float* sl = p.slots + ((long)b * NT + j) * p.slot;
@@ -1198,7 +1270,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
 #pragma unroll
         for (int k = 0; k < KNMAX; ++k) if (k < Kn) sl[A + k * A + a] = dwp[k];
     }
-    if (tid == 0) p.slots[((long)b * NT + j) * p.slot + A * (1 + Kn)] = dbg;
+    if (dbg != 0.f) atomicAdd(p.slots + ((long)b * NT + j) * p.slot + A * (1 + Kn), dbg);     // slots are zero on entry
 }
 
 struct PersistPlanB { bool ok; int TE, NT, UPW, CPW, R4, CG2, QG2, VG2, NG2; size_t lds, status_bytes, xbuf_bytes, w16_bytes, dg_bytes, total; };
@@ -1220,6 +1292,7 @@ PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
     pl.R4 = (4 * d.Dd + 7) & ~7;
     auto even = [](int x) { return (x + 1) & ~1; };
     pl.CG2 = even((pl.CPW + pl.UPW + 1) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even((TE + pl.UPW + 1) / 2);
+    if (pl.NT * pl.QG2 * 2 < NPB * 64 * 11) return pl;       // s_qst doubles as the stage of the polling waves' partial accumulators
     const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.CG2, pl.QG2, pl.NG2);
     pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
     if (pl.lds > 160 * 1024 - 4096) return pl;

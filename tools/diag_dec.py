@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'e2e-asr-pytorch
 import torch, yaml
 from src import hipabi as H
 H._lib = None
-lib = ctypes.CDLL(os.path.join(ROOT, 'e2e-asr-pytorch_amd', 'lib', 'diag', 'libasr_hip_diag.so'))
+lib = ctypes.CDLL(os.environ.get('ASR_DIAG_LIB', os.path.join(ROOT, 'e2e-asr-pytorch_amd', 'lib', 'diag', 'libasr_hip_diag.so')))
 for name, argtypes in H.SIGNATURES.items():
     fn = getattr(lib, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
 for name, (rt, at) in H._RESTYPES.items():

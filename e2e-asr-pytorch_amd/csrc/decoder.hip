@@ -1248,6 +1248,12 @@ extern "C" size_t asr_att_decoder_bwd_status_offset(const asr_dec_dims_t* dims) 
     return bwd_layout(*dims).pwork;
 }
 
+// tiles per utterance of the persistent backward launch (0: the shape has no plan and the per-step kernels run)
+extern "C" int asr_att_decoder_bwd_persistent_tiles(const asr_dec_dims_t* dims) {
+    if (!dims) return 0;
+    return bwd_layout(*dims).ntp;
+}
+
 extern "C" size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims) {
     if (!dims) return 0;
     return bwd_layout(*dims).total;

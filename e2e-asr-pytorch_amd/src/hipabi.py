@@ -88,6 +88,7 @@ _RESTYPES = {
     'asr_att_decoder_fwd_work_bytes': (_sz, [_P(DecDims)]),
     'asr_att_decoder_set_persistent': (ctypes.c_int, [_i]),
     'asr_att_decoder_bwd_status_offset': (_sz, [_P(DecDims)]),
+    'asr_att_decoder_bwd_persistent_tiles': (ctypes.c_int, [_P(DecDims)]),
 }
 
 

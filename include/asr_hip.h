@@ -200,6 +200,10 @@ size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims);
 /* bit 0 / bit 1: run the teacher-forced forward / backward loop as one persistent launch where the shape has a plan
  * (default on, env ASR_DEC_PERSIST / ASR_DEC_PERSIST_BWD); returns the previous flags.  For A/B tests. */
 int asr_att_decoder_set_persistent(int flags);
+/* tiles per utterance when asr_att_decoder_bwd runs the whole loop as ONE persistent launch (0: no plan for this shape,
+ * the per-step kernels run); offset of that launch's 4 KB status block (abort word first) inside the workspace. */
+int asr_att_decoder_bwd_persistent_tiles(const asr_dec_dims_t* dims);
+size_t asr_att_decoder_bwd_status_offset(const asr_dec_dims_t* dims);
 /* bytes of state->work that let asr_att_decoder_fwd run the teacher-forced loop as ONE persistent launch (0: shape has no plan) */
 size_t asr_att_decoder_fwd_work_bytes(const asr_dec_dims_t* dims);
 /* dlogits (B,L,V) in; denc (B,Tp,E) accumulated (+=); parameter gradients accumulated into `grads`.

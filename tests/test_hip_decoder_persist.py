@@ -61,10 +61,13 @@ def test_persistent_forward_matches_step_kernels(B, Tp, L):
         assert err < 2e-3, 'conv row %d differs by %g' % (bi, err)
 
 
-@pytest.mark.parametrize('B,Tp,L', [(16, 600, 10), (3, 170, 9), (9, 333, 7), (4, 18, 5)])
-def test_persistent_backward_matches_step_kernels(B, Tp, L):
+# (B, T', L, tiles of the persistent plan: 0 = no plan for the shape, both runs take the per-step kernels)
+@pytest.mark.parametrize('B,Tp,L,tiles', [(16, 600, 10, 15), (16, 577, 4, 15), (8, 1000, 6, 0), (5, 640, 1, 16), (2, 230, 5, 15),
+                                          (3, 170, 9, 0), (9, 333, 7, 0), (4, 18, 5, 0)])
+def test_persistent_backward_matches_step_kernels(B, Tp, L, tiles):
     """Gradients of the decoder (all parameters + encoder output) with the loop as one persistent launch vs the per-step
-    kernels, from the same forward state."""
+    kernels, from the same forward state.  Covers both tile sizes (40 and 16 frames), a ragged last tile, one cluster per
+    XCD and two, a single step, and shapes without a plan."""
     from src import hipabi as H
     from src import functions as F
     model = _model('librispeech_asr.yaml')
@@ -78,6 +81,9 @@ def test_persistent_backward_matches_step_kernels(B, Tp, L):
     dlog = (torch.randn(B, L, 31, generator=g) * 0.1).cuda()
     names = [n for n, _ in model.named_parameters() if n.startswith(('decoder', 'attention', 'pre_embed'))]
     out = {}
+    d = F._dec_dims(model, B, Tp, L)
+    assert int(H.lib().asr_att_decoder_bwd_persistent_tiles(ctypes.byref(d))) == tiles
+    off = int(H.lib().asr_att_decoder_bwd_status_offset(ctypes.byref(d)))
     old = H.lib().asr_att_decoder_set_persistent(3)
     try:
         for mode in (3, 1):
@@ -89,6 +95,8 @@ def test_persistent_backward_matches_step_kernels(B, Tp, L):
             torch.cuda.synchronize()
             out[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if n in names}
             out[mode]['enc'] = enc.grad.detach().clone()
+            if mode == 3 and tiles:
+                assert int(model._last_dec_bwd_ws[off:off + 4].view(torch.int32).item()) == 0, 'persistent backward raised its abort word'
     finally:
         H.lib().asr_att_decoder_set_persistent(old)
     for n in out[3]:

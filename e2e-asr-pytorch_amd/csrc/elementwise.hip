@@ -38,6 +38,42 @@ __global__ void dropout_downsample_kernel(DsP p) {
     }
 }
 
+// Same map for D % 4 == 0 and 16-byte aligned buffers: a thread owns four consecutive elements of a row of y - ONE Philox
+// block (dropout_keep draws element idx from word idx & 3 of block idx >> 2), one 16-byte load, one 16-byte store;
+// the row decomposition is done in 32-bit arithmetic per (b,t) row.
+template <bool BWD>
+__global__ void dropout_downsample_vec4_kernel(DsP p) {
+    const int D4 = p.D >> 2;
+    const long rows = (long)p.B * p.T, total4 = rows * D4;
+    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < total4; j += (long)gridDim.x * blockDim.x) {
+        const long row = j / D4;
+        const int k4 = (int)(j - row * D4);
+        const int b = (int)(row / p.T), t = (int)(row - (long)b * p.T);
+        long zi = -1;
+        if (p.style == 0) {
+            if (t % p.rate == 0 && t / p.rate < p.T2) zi = ((long)b * p.T2 + t / p.rate) * p.D + 4 * k4;
+        } else {
+            if (t < p.T2 * p.rate) zi = ((long)b * p.T2 + t / p.rate) * ((long)p.D * p.rate) + (long)(t % p.rate) * p.D + 4 * k4;
+        }
+        const long i = 4 * j;                                            // flat index in y: a multiple of 4 = one Philox block
+        if (!BWD && zi < 0) continue;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (zi >= 0) {
+            const float4 x = *reinterpret_cast<const float4*>(p.src + (BWD ? zi : i));
+            uint32_t r[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (p.thresh != 0) {
+                const uint64_t blk = (uint64_t)i >> 2;
+                philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
+            }
+            v.x = (r[0] >= p.thresh) ? x.x * p.scale : 0.f;
+            v.y = (r[1] >= p.thresh) ? x.y * p.scale : 0.f;
+            v.z = (r[2] >= p.thresh) ? x.z * p.scale : 0.f;
+            v.w = (r[3] >= p.thresh) ? x.w * p.scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(p.dst + (BWD ? i : zi)) = v;
+    }
+}
+
 __global__ void dropout_mask_kernel(float* mask, long n, uint32_t thresh, uint64_t seed) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         mask[i] = (thresh == 0 || dropout_keep(seed, (uint64_t)i, thresh)) ? 1.f : 0.f;
@@ -168,7 +204,10 @@ extern "C" int asr_dropout_downsample_fwd(const float* y, float* z, int B, int T
     ASR_REQUIRE(y && z && B > 0 && T > 0 && D > 0 && T2 > 0 && rate >= 1, ASR_E_ARG, "asr_dropout_downsample_fwd: bad args");
     ASR_REQUIRE(p >= 0.f && p < 1.f, ASR_E_ARG, "asr_dropout_downsample_fwd: p must be in [0,1)");
     DsP a{y, z, B, T, D, T2, rate, style, 1.f / (1.f - p), drop_thresh(p), seed};
-    hipLaunchKernelGGL(dropout_downsample_kernel<false>, dim3(grid_for((long)B * T * D)), dim3(256), 0, (hipStream_t)stream, a);
+    if ((D & 3) == 0 && (((uintptr_t)y | (uintptr_t)z) & 15) == 0)
+        hipLaunchKernelGGL(dropout_downsample_vec4_kernel<false>, dim3(grid_for((long)B * T * (D / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(dropout_downsample_kernel<false>, dim3(grid_for((long)B * T * D)), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_dropout_downsample_fwd");
     return ASR_OK;
 }
@@ -177,7 +216,10 @@ extern "C" int asr_dropout_downsample_bwd(const float* dz, float* dy, int B, int
                                           float p, uint64_t seed, asr_stream_t stream) {
     ASR_REQUIRE(dz && dy && B > 0 && T > 0 && D > 0 && T2 > 0 && rate >= 1, ASR_E_ARG, "asr_dropout_downsample_bwd: bad args");
     DsP a{dz, dy, B, T, D, T2, rate, style, 1.f / (1.f - p), drop_thresh(p), seed};
-    hipLaunchKernelGGL(dropout_downsample_kernel<true>, dim3(grid_for((long)B * T * D)), dim3(256), 0, (hipStream_t)stream, a);
+    if ((D & 3) == 0 && (((uintptr_t)dz | (uintptr_t)dy) & 15) == 0)
+        hipLaunchKernelGGL(dropout_downsample_vec4_kernel<true>, dim3(grid_for((long)B * T * (D / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(dropout_downsample_kernel<true>, dim3(grid_for((long)B * T * D)), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_dropout_downsample_bwd");
     return ASR_OK;
 }

@@ -16,7 +16,7 @@ def per_kernel(path, counter):
         if r['Counter_Name'] != counter:
             continue
         name = r['Kernel_Name']
-        for key in ('lstm_fwd_p2', 'lstm_bwd_p2', 'att_bwd_energy_kernel', 'att_energy_kernel', 'gemm_kernel'):
+        for key in ('lstm_fwd_p2', 'lstm_bwd_p2', 'dec_fwd_persist', 'dec_bwd_persist', 'att_bwd_energy_kernel', 'att_energy_kernel', 'gemm_kernel'):
             if key in name:
                 a = acc.setdefault(key, [0, 0.0])
                 a[0] += 1

@@ -108,3 +108,52 @@ def test_persistent_backward_matches_step_kernels(B, Tp, L, tiles):
             continue
         rel = float((a - b_).norm() / (b_.norm() + 1e-12))
         assert rel < 2e-2, '%s: relative difference %g' % (n, rel)
+
+
+def test_training_trajectory_persistent_vs_step_kernels():
+    """Six optimizer steps of the full-size model (config/librispeech_asr.yaml, dropout off) at a shape with a persistent
+    plan, once with both decoder loops as single launches and once with the per-step kernels: the loss trajectory and the
+    final parameters must agree.  Exercises repeated launches (tag epochs, recycled exchange buffers) through the whole
+    path: front of the model, both losses, clip, Adadelta."""
+    from src import hipabi as H
+    from src.asr import ASR
+    from src.optim import Optimizer
+    from src.step import train_step
+    from src.synthetic import librispeech_shaped_batch
+    from src.util import CTCLoss, CrossEntropyLoss
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'e2e-asr-pytorch_amd')
+    config = yaml.safe_load(open(os.path.join(root, 'config', 'librispeech_asr.yaml')))
+    mc = config['model']
+    mc['encoder']['dropout'] = [0.0] * len(mc['encoder']['dropout'])
+    mc['decoder']['dropout'] = 0.0
+    B, T, L = 4, 1200, 24
+    feat, feat_len, txt = librispeech_shaped_batch(B, T, 160, L, 31, seed=11, device='cuda')
+    runs = {}
+    old = H.lib().asr_att_decoder_set_persistent(3)
+    try:
+        for flags in (3, 0):
+            H.lib().asr_att_decoder_set_persistent(flags)
+            torch.manual_seed(0)
+            model = ASR(160, 31, B, prec='bf16', seed=21, **mc).cuda().train()
+            if flags == 3:
+                d = __import__('src.functions', fromlist=['_dec_dims'])._dec_dims(model, B, T // 2, L)
+                assert int(H.lib().asr_att_decoder_bwd_persistent_tiles(ctypes.byref(d))) > 0
+                assert int(H.lib().asr_att_decoder_fwd_work_bytes(ctypes.byref(d))) > 0
+            opt = Optimizer(model.parameters(), 'Adadelta', 1.0, 1e-8)
+            ctc, att = CTCLoss(blank=0, zero_infinity=False), CrossEntropyLoss(ignore_index=0)
+            losses = []
+            for _ in range(6):
+                out = train_step(model, opt, ctc, att, feat, feat_len, txt, L, tf_rate=1.0, clip=5.0)
+                losses.append(float(out['total_loss']))
+            runs[flags] = (losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().cpu())
+    finally:
+        H.lib().asr_att_decoder_set_persistent(old)
+    la, lb = runs[3][0], runs[0][0]
+    assert all(abs(x) < 1e4 and x == x for x in la), la
+    assert la[-1] < la[0], 'loss did not go down: %s' % la
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 5e-3 * abs(y), 'loss trajectories differ: %s vs %s' % (la, lb)
+    pa, pb = runs[3][1], runs[0][1]
+    cos = float((pa * pb).sum() / (pa.norm() * pb.norm()))
+    rel = float((pa - pb).norm() / pb.norm())
+    assert cos > 0.99999 and rel < 2e-3, 'parameters after 6 steps: cosine %.7f, relative difference %.3g' % (cos, rel)

@@ -661,7 +661,7 @@ struct PB {
     const float* wqT;               // (Dd x A)
     u64* xbuf;
     unsigned* status;
-    int slot, NT, UPW, CPW, R4;
+    int slot, NT, TE, UPW, CPW, R4;
     int CG2, QG2, VG2, NG2;         // granules per producer record (even)
     int allow_local;
     unsigned epoch;
@@ -795,13 +795,15 @@ __device__ __forceinline__ void poll_copy(const u64* src, int n16, float* dst, i
         }                                                                                                              \
     }
 
-template <int KNMAX, int TE>
+// TEC: frames per tile as a compile-time constant (the bench shape), 0: taken from the plan (any multiple of 4 up to 40)
+template <int KNMAX, int TEC>
 __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_bar;
     __shared__ float s_red[8];
     constexpr int KP = (KNMAX + 3) & ~3;
-    constexpr int MT = (TE + 15) / 16;
+    const int TE = TEC ? TEC : p.TE;
+    const int MT = (TE + 15) / 16;
     const asr_dec_dims_t& d = p.d;
     const int id = blockIdx.x, xcd = id & 7, slot_id = id >> 3;
     const int cb = slot_id / p.NT, j = slot_id - cb * p.NT;
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     const int nout = p.CPW + p.UPW;
     // The sweep is VALU-bound and ncw compute waves share 4 SIMDs, so the columns of the LAST compute wave ("tail", a >= 64*(ncw-1))
     // are swept by four waves - that wave and the three polling waves - a quarter of the tile's frames each.
-    const int xa0 = 64 * (ncw - 1), fq = (TE + 3) / 4;
+    const int xa0 = 64 * (ncw - 1), fq = 2 * ((TE + 7) / 8);       // an even number of frames per quarter
     // rows of the transposed cell weights are register-resident: compute wave w has outputs w + ncw*o (o < RCB), polling
     // wave pw has RCB*ncw + pw + NPB*o (o < RPB)
     __syncthreads();
@@ -1179,7 +1181,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         if (t > 0) {
             // datt_next[tau'] = sum_k sum_j W_conv[k][j] * dconv[k][tau' - j + Ks] for the tile's frames:
             // item = (tap range, kernel, group of 4 outputs); four taps per round from three 16-byte LDS reads
-            constexpr int ngrp = TE / 4;
+            const int ngrp = TE / 4;
             const int nitem = Kn * ngrp;
             const int parts = max(1, min(4, nct / nitem));
             const int gpp = (WT / 4 + parts - 1) / parts;                 // tap groups per part
@@ -1281,20 +1283,25 @@ PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
     const int cpx = cdiv(d.B, 8);
     const int ncw = cdiv(d.A, 64), nct = 64 * ncw;
     if (d.Dd > nct || d.E > 2 * nct || d.E > 640 || d.Tp > 4 * nct) return pl;
-    int TE = 0;
-    const int cand[] = {16, 40};
-    for (int i = 0; i < 2; ++i) { const int nt = cdiv(d.Tp, cand[i]); if (nt <= 30 && cpx * nt <= 32 && 8 * cand[i] <= nct) { TE = cand[i]; break; } }
-    if (!TE) return pl;
-    pl.TE = TE; pl.NT = cdiv(d.Tp, TE);
-    pl.UPW = cdiv(d.Dd, pl.NT); pl.CPW = cdiv(d.E, pl.NT);
-    if (pl.UPW > 64 || pl.UPW + pl.CPW > RCB * ncw + RPB * NPB || d.Kn * TE > 2 * nct || (TE + pl.UPW + 1) / 2 + 1 > nct) return pl;
     pl.R4 = (4 * d.Dd + 7) & ~7;
     auto even = [](int x) { return (x + 1) & ~1; };
-    pl.CG2 = even((pl.CPW + pl.UPW + 1) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even((TE + pl.UPW + 1) / 2);
-    if (pl.NT * pl.QG2 * 2 < NPB * 64 * 11) return pl;       // s_qst doubles as the stage of the polling waves' partial accumulators
-    const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.CG2, pl.QG2, pl.NG2);
-    pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
-    if (pl.lds > 160 * 1024 - 4096) return pl;
+    // frames per tile: the smallest multiple of 4 (most tiles, fewest weight rows and sweep frames per workgroup) whose tiles
+    // fit the XCD (32 CUs per XCD, ceil(B/8) clusters each), the register-resident weight rows and the LDS
+    bool found = false;
+    for (int TE = 8; TE <= 40 && !found; TE += 4) {
+        const int nt = cdiv(d.Tp, TE);
+        if (nt > 30 || cpx * nt > 32 || 8 * TE > nct || d.Kn * TE > 2 * nct) continue;
+        pl.TE = TE; pl.NT = nt;
+        pl.UPW = cdiv(d.Dd, nt); pl.CPW = cdiv(d.E, nt);
+        if (pl.UPW > 64 || pl.UPW + pl.CPW > RCB * ncw + RPB * NPB || (TE + pl.UPW + 1) / 2 + 1 > nct) continue;
+        pl.CG2 = even((pl.CPW + pl.UPW + 1) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((TE * d.Kn + 1) / 2); pl.NG2 = even((TE + pl.UPW + 1) / 2);
+        if (pl.NT * pl.QG2 * 2 < NPB * 64 * 11) continue;       // s_qst doubles as the stage of the polling waves' partial accumulators
+        const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.CG2, pl.QG2, pl.NG2);
+        pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
+        if (pl.lds > 160 * 1024 - 4096) continue;
+        found = true;
+    }
+    if (!found) return pl;
     pl.status_bytes = 4096;
     pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.CG2 + pl.QG2 + pl.VG2 + pl.NG2) * sizeof(u64));
     pl.w16_bytes = align_up256((size_t)(d.Dd + d.E + d.Dd) * pl.R4 * 2);
@@ -1339,7 +1346,7 @@ int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
     if (allow < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); allow = (e && e[0] == '0') ? 0 : 1; }
     if (delay < 0) { const char* e = getenv("ASR_DEC_BWD_POLL_DELAY"); delay = e ? atoi(e) : 0; }
     PB p{d, w, s, (const unsigned short*)s.enc16, enc_len, dhs, dxin, dq, dkey, slots, dgates, w16, wqT, xbuf, status,
-         slot, pl.NT, pl.UPW, pl.CPW, pl.R4, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, epoch_counter++, delay};
+         slot, pl.NT, pl.TE, pl.UPW, pl.CPW, pl.R4, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, epoch_counter++, delay};
     const int cpx = cdiv(d.B, 8), ncw = cdiv(d.A, 64);
     const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
 #define DPB_LAUNCH(KN_, TE_)                                                                                                    \
@@ -1348,8 +1355,8 @@ int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
         if (!attr) { hipFuncSetAttribute((const void*)dec_bwd_persist<KN_, TE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr = true; } \
         hipLaunchKernelGGL((dec_bwd_persist<KN_, TE_>), grid, block, pl.lds, st, p);                                              \
     }
-    if (d.Kn <= 4) { if (pl.TE == 16) DPB_LAUNCH(4, 16) else DPB_LAUNCH(4, 40) }
-    else { if (pl.TE == 16) DPB_LAUNCH(10, 16) else DPB_LAUNCH(10, 40) }
+    if (d.Kn <= 4) { if (pl.TE == 40) DPB_LAUNCH(4, 40) else DPB_LAUNCH(4, 0) }
+    else { if (pl.TE == 40) DPB_LAUNCH(10, 40) else DPB_LAUNCH(10, 0) }
 #undef DPB_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { asr_set_error("asr_att_decoder_bwd(persistent): launch failed: %s", hipGetErrorString(e)); return ASR_E_LAUNCH; }

@@ -61,13 +61,13 @@ def test_persistent_forward_matches_step_kernels(B, Tp, L):
         assert err < 2e-3, 'conv row %d differs by %g' % (bi, err)
 
 
-# (B, T', L, tiles of the persistent plan: 0 = no plan for the shape, both runs take the per-step kernels)
-@pytest.mark.parametrize('B,Tp,L,tiles', [(16, 600, 10, 15), (16, 577, 4, 15), (8, 1000, 6, 0), (5, 640, 1, 16), (2, 230, 5, 15),
-                                          (3, 170, 9, 0), (9, 333, 7, 0), (4, 18, 5, 0)])
+# (B, T', L, whether the shape has a persistent plan; without one both runs take the per-step kernels)
+@pytest.mark.parametrize('B,Tp,L,tiles', [(16, 600, 10, True), (16, 577, 4, True), (16, 400, 5, True), (16, 300, 4, True), (5, 640, 1, True),
+                                          (2, 230, 5, True), (8, 1000, 6, False), (3, 170, 9, True), (9, 333, 7, False), (4, 18, 5, False)])
 def test_persistent_backward_matches_step_kernels(B, Tp, L, tiles):
     """Gradients of the decoder (all parameters + encoder output) with the loop as one persistent launch vs the per-step
-    kernels, from the same forward state.  Covers both tile sizes (40 and 16 frames), a ragged last tile, one cluster per
-    XCD and two, a single step, and shapes without a plan."""
+    kernels, from the same forward state.  Covers the compile-time tile size (40 frames) and run-time ones (8..28), a ragged
+    last tile, one cluster per XCD and two, a single step, and shapes without a plan."""
     from src import hipabi as H
     from src import functions as F
     model = _model('librispeech_asr.yaml')
@@ -82,7 +82,7 @@ def test_persistent_backward_matches_step_kernels(B, Tp, L, tiles):
     names = [n for n, _ in model.named_parameters() if n.startswith(('decoder', 'attention', 'pre_embed'))]
     out = {}
     d = F._dec_dims(model, B, Tp, L)
-    assert int(H.lib().asr_att_decoder_bwd_persistent_tiles(ctypes.byref(d))) == tiles
+    assert (int(H.lib().asr_att_decoder_bwd_persistent_tiles(ctypes.byref(d))) > 0) == tiles
     off = int(H.lib().asr_att_decoder_bwd_status_offset(ctypes.byref(d)))
     old = H.lib().asr_att_decoder_set_persistent(3)
     try:

@@ -75,6 +75,13 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 #undef DPB_STEP
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// sum over aligned groups of 8 lanes (every lane of the group gets it): quad swaps + half-row mirror, no LDS permutes
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    return v;
+}
 __device__ __forceinline__ float wave_max_dpp(float v) {
 #define DPB_STEP(CTRL, RMASK) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false)));
     DPB_STEP(0xB1, 0xf)
@@ -1081,7 +1088,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                          __uint_as_float(x[u].w << 16) * db.z + __uint_as_float(x[u].w & 0xffff0000u) * db.w;
                 }
             }
-            v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            v = sum8_dpp(v);
             float dot = 0.f;
 #pragma unroll
             for (int h = 0; h < 2; ++h) if (tid + nct * h < E) dot += ctx2[h] * s_dcx[tid + nct * h];
@@ -1225,7 +1232,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
                 const int i = tid >> 3, sub = tid & 7;
                 float sv = 0.f;
                 if (i < TE) for (int r = sub; r < parts * Kn; r += 8) sv += s_pt[(long)r * TE + i];
-                sv += __shfl_xor(sv, 4); sv += __shfl_xor(sv, 2); sv += __shfl_xor(sv, 1);
+                sv = sum8_dpp(sv);
                 if (i < TE && sub == 0) s_de[i] = sv;
             }
             DP_MARK(15)

@@ -170,6 +170,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    t_host = time.perf_counter() - t0           # host time to ENQUEUE the steps (diagnostic: how far the CPU runs ahead of the GPU)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -238,7 +239,7 @@ def main():
         'config': {'workload': 'config/librispeech_asr.yaml (vgg 0, 4xBiLSTM-320, joint CTC-att 0.5), B=%d x T=%d x D=%d per GPU, L=%d, '
                                'delta+SpecAugment on GPU, fwd+losses+bwd+grad-allreduce+clip+Adadelta, dropout on' % (B, T, Dfeat, L),
                    'global_batch': B * world, 'frames_per_utt': T, 'parallelism': 'dp%d' % world},
-        'valid_frames_per_s': valid / dt, 'loss': loss,
+        'valid_frames_per_s': valid / dt, 'loss': loss, 'host_enqueue_ms_per_step': t_host / args.steps * 1e3,
         'stage_ms_per_step': {k: v / args.steps for k, v in tot.items() if k != 'asr_gemm'},
         'roofline': roof, 'roofline_gemm': gemm, 'cpu_baseline': cpu,
     }

@@ -1279,6 +1279,16 @@ extern "C" size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims
     return bwd_layout(*dims).total;
 }
 
+// reduction slices of a weight-gradient contraction (out_rows x out_cols, reduction over `depth` rows): these outputs are a
+// handful of 128x128 tiles with a reduction thousands of rows deep, i.e. a few workgroups walking ~100 dependent k-steps;
+// slices of >= 256 rows spread them over about one round of workgroups (fp32 atomics into the gradient)
+static int wgrad_slices(int out_rows, int out_cols, int depth) {
+    const int tiles = cdiv(out_rows, 128) * cdiv(out_cols, 128);
+    int s = 768 / tiles;
+    if (s > depth / 256) s = depth / 256;
+    return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
 extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights, const asr_dec_grads_t* grads,
                                    const float* enc, const int64_t* enc_len, const asr_dec_state_t* state,
                                    const float* dlogits, float* denc,
@@ -1330,7 +1340,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
                   ASR_ACT_NONE, 0, 1, 1, 0, 0, 0, 0, 0, prec, stream);
     if (rc != ASR_OK) return rc;
     rc = asr_gemm(dlogits, state->hs + (size_t)(d.NL - 1) * d.Dd, grads->Wc, nullptr, d.V, d.Dd, BL, d.V, SW, d.Dd, 0, 0,
-                  ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, 0, 0, prec, stream);
+                  ASR_ACT_NONE, 1, wgrad_slices(d.V, d.Dd, BL), 1, 0, 0, 0, 0, 0, prec, stream);
     if (rc != ASR_OK) return rc;
     rc = asr_colsum(dlogits, d.V, BL, d.V, grads->bc, stream);
     if (rc != ASR_OK) return rc;
@@ -1411,16 +1421,18 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
         const int Kx = (l == 0) ? XW : d.Dd;
         const float* xl = (l == 0) ? state->xin : state->hs + (size_t)(l - 1) * d.Dd;
         const long ldx = (l == 0) ? XW : SW;
-        rc = asr_gemm(dg, xl, grads->Wih[l], nullptr, 4 * d.Dd, Kx, BL, ldg, ldx, Kx, 0, 0, ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, 0, 0, prec, stream);
+        rc = asr_gemm(dg, xl, grads->Wih[l], nullptr, 4 * d.Dd, Kx, BL, ldg, ldx, Kx, 0, 0, ASR_ACT_NONE, 1, wgrad_slices(4 * d.Dd, Kx, BL), 1, 0, 0, 0, 0,
+                      0, prec, stream);
         if (rc != ASR_OK) return rc;
         rc = asr_gemm(dg, state->hs + (size_t)l * d.Dd, grads->Whh[l], nullptr, 4 * d.Dd, d.Dd, BL, ldg, SW, d.Dd, 0, 0, ASR_ACT_NONE,
-                      1, 1, 1, 0, 0, 0, d.L, -1, prec, stream);
+                      1, wgrad_slices(4 * d.Dd, d.Dd, BL), 1, 0, 0, 0, d.L, -1, prec, stream);
         if (rc != ASR_OK) return rc;
         rc = asr_colsum2(dg, ldg, BL, 4 * d.Dd, grads->bih[l], grads->bhh[l], stream);
         if (rc != ASR_OK) return rc;
     }
     // query projection: dW_q += dqpre^T hcat_{t-1}, db_q += colsum(dqpre)
-    rc = asr_gemm(p.dq, state->hs, grads->Wq, nullptr, d.A, d.Q, BL, d.A, d.Q, d.Q, 0, 0, ASR_ACT_NONE, 1, 1, 1, 0, 0, 0, d.L, -1, prec, stream);
+    rc = asr_gemm(p.dq, state->hs, grads->Wq, nullptr, d.A, d.Q, BL, d.A, d.Q, d.Q, 0, 0, ASR_ACT_NONE, 1, wgrad_slices(d.A, d.Q, BL), 1, 0, 0, 0, d.L, -1,
+                  prec, stream);
     if (rc != ASR_OK) return rc;
     rc = asr_colsum(p.dq, d.A, BL, d.A, grads->bq, stream);
     if (rc != ASR_OK) return rc;
@@ -1436,7 +1448,7 @@ extern "C" int asr_att_decoder_bwd(const asr_dec_dims_t* dims, const asr_dec_wei
     rc = asr_act_bwd(p.dkey, state->key, dkeypre, (long)d.B * d.Tp * d.A, ASR_ACT_TANH, stream);
     if (rc != ASR_OK) return rc;
     const int M = d.B * d.Tp;
-    const int splits = M >= 4096 ? 8 : 1;
+    const int splits = wgrad_slices(d.A, d.E, M);
     rc = asr_gemm(dkeypre, enc, grads->Wk, nullptr, d.A, d.E, M, d.A, d.E, d.E, 0, 0, ASR_ACT_NONE, 1, splits, 1, 0, 0, 0, 0, 0, prec, stream);
     if (rc != ASR_OK) return rc;
     rc = asr_colsum(dkeypre, d.A, M, d.A, grads->bk, stream);

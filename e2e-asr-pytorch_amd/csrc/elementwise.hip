@@ -96,8 +96,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     float s = 0.f;
-    if (col < N)
-        for (int r = r0 + grp; r < r1; r += 4) s += A[(long)r * lda + col];
+    if (col < N) {
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = r0 + grp;
+        for (; r + 12 < r1; r += 16) {                      // four independent loads in flight
+            const float a0 = A[(long)r * lda + col], a1 = A[(long)(r + 4) * lda + col];
+            const float a2 = A[(long)(r + 8) * lda + col], a3 = A[(long)(r + 12) * lda + col];
+            s += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; r < r1; r += 4) s += A[(long)r * lda + col];
+        s += s1 + s2 + s3;
+    }
     red[grp][threadIdx.x & 63] = s;
     __syncthreads();
     if (grp == 0 && col < N) {
@@ -241,7 +250,8 @@ extern "C" int asr_act_bwd(const float* dout, const float* out, float* dpre, lon
 
 extern "C" int asr_colsum2(const float* A, long lda, int M, int N, float* out, float* out2, asr_stream_t stream) {
     ASR_REQUIRE(A && out && M > 0 && N > 0 && lda >= N, ASR_E_ARG, "asr_colsum: bad args");
-    const int rows_per_block = 512;
+    int rows_per_block = 512;                               // small matrices: more, shorter row blocks (about one round of workgroups)
+    while (rows_per_block > 32 && (long)cdiv(N, 64) * cdiv(M, rows_per_block) < 1024) rows_per_block >>= 1;
     dim3 grid(cdiv(N, 64), cdiv(M, rows_per_block));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, lda, M, N, out, out2, rows_per_block);
     ASR_LAUNCH_CHECK("asr_colsum");

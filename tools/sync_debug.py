@@ -1,0 +1,33 @@
+import os, sys, warnings
+ROOT='/root/repo'
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'e2e-asr-pytorch_amd'))
+import torch, yaml
+from src.asr import ASR
+from src.optim import Optimizer
+from src.step import train_step
+from src.synthetic import librispeech_shaped_batch
+from src.util import CTCLoss, CrossEntropyLoss
+from src.audio import Delta, Augment
+config = yaml.safe_load(open(os.path.join(ROOT, 'e2e-asr-pytorch_amd', 'config', 'librispeech_asr.yaml')))
+model = ASR(160, 31, 16, prec='bf16', seed=1, **config['model']).cuda().train()
+hp = config['hparas']
+opt = Optimizer(model.parameters(), hp['optimizer'], hp['lr'], hp['eps'])
+ctc, att = CTCLoss(blank=0, zero_infinity=False), CrossEntropyLoss(ignore_index=0)
+fbank, feat_len, txt = librispeech_shaped_batch(16, 1200, 80, 180, 31, seed=1, device='cuda')
+txt_len = (txt != 0).sum(-1)
+delta = Delta(1, 2).cuda(); aug = Augment(seed=3).cuda()
+def step():
+    feat, _ = delta(fbank, feat_len)
+    feat, _ = aug(feat, feat_len)
+    return train_step(model, opt, ctc, att, feat, feat_len, txt, 180, tf_rate=1.0, clip=5.0, txt_len=txt_len)
+for _ in range(2): step()
+torch.cuda.synchronize()
+torch.cuda.set_sync_debug_mode('warn')
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    step()
+    torch.cuda.set_sync_debug_mode('default')
+    print('sync warnings:', len(w))
+    import traceback
+    for x in w[:20]:
+        print(x.filename, x.lineno, str(x.message)[:100])

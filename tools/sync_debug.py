@@ -1,5 +1,7 @@
+"""Runs one training step of the bench workload under torch's synchronisation debug mode and lists every host<->device
+synchronisation it triggers (expected: none - the step never waits for the GPU)."""
 import os, sys, warnings
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'e2e-asr-pytorch_amd'))
 import torch, yaml
 from src.asr import ASR

@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--vgg', type=int, default=None, help='override model.encoder.vgg (1: VGGExtractor, 5: VGGExtractor_LN) for the SURVEY D3 variants')
     ap.add_argument('--waveform', action='store_true', help='resident input = 16 kHz waveforms; the GPU fbank (asr_fbank) runs inside the step')
     ap.add_argument('--host-input', action='store_true', help='the batch (fbank, lengths, tokens) is handed over in pinned host memory and copied to the GPU inside every step: the PCIe-inclusive rate of DESIGN.md section 6 (never the headline value)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend for --gpus N > 1 (nccl = RCCL over xGMI; gloo only with --dry-run)')
+    ap.add_argument('--dry-run', action='store_true', help='start the ranks, form the process group, exchange one all-gather and print the JSON line without touching a GPU (CPU test of the launch path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
@@ -105,15 +107,68 @@ def cpu_baseline(cfg_model, D, V, seconds, B=16, T=1200, L=180):
                       % (B, T, L, n, dt)}
 
 
+def workload_string(config, args, Dfeat):
+    return ('config/librispeech_asr.yaml (vgg %d, 4xBiLSTM-320, joint CTC-att 0.5), B=%d x T=%d x D=%d per GPU, L=%d, '
+            '%sdelta+SpecAugment on GPU, fwd+losses+bwd+grad-allreduce+clip+Adadelta, dropout on'
+            % (config['model']['encoder']['vgg'], args.batch, args.frames, Dfeat, args.tokens, 'waveform in: GPU fbank + ' if args.waveform else ''))
+
+
+# the PMC files of round 2 carry no workload field: they were collected on the default command
+LEGACY_PMC_WORKLOAD = ('config/librispeech_asr.yaml (vgg 0, 4xBiLSTM-320, joint CTC-att 0.5), B=16 x T=1200 x D=160 per GPU, L=180, '
+                       'delta+SpecAugment on GPU, fwd+losses+bwd+grad-allreduce+clip+Adadelta, dropout on')
+
+
 def log(msg):
     print('[bench] ' + msg, file=sys.stderr, flush=True)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this script under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and exit with their status.  Nothing has touched a GPU in this process, so the
+    children are ordinary child processes, not a re-exec of a process that owns the device."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('no WORLD_SIZE in the environment: starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """Launch-path check without a GPU: every rank reports in through one all-gather; rank 0 prints the line."""
+    import torch.distributed as dist
+    ranks = [rank]
+    if world > 1:
+        mine = torch.tensor([rank], dtype=torch.int64)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        dist.barrier()
+        ranks = sorted(int(x) for x in got)
+    if rank == 0:
+        print(json.dumps({'metric': 'audio frames/sec (fwd+bwd) LibriSpeech-100 joint CTC-att', 'value': None, 'dry_run': True,
+                          'n_gpus': world, 'ranks': ranks, 'backend': args.backend if world > 1 else None,
+                          'steps': args.steps, 'warmup': args.warmup}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.backend == 'gloo' and not args.dry_run:
+        sys.exit('--backend gloo is for --dry-run only: the step runs on the GPU over RCCL')
     from src import dist as D_
-    rank, world, local = D_.init_from_env('nccl' if args.gpus > 1 else None)
-    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node %d' % args.gpus
+    rank, world, local = D_.init_from_env(args.backend if args.gpus > 1 else None)
+    if world != args.gpus:
+        sys.exit('bench.py --gpus %d was started with WORLD_SIZE=%d: the process group must have exactly one rank per GPU asked for' % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local)
     from src import hipabi as H
     from src.asr import ASR
@@ -167,9 +222,15 @@ def main():
 
     import contextlib
 
+    use_work = H.overlap_enabled() and (world == 1 or H.overlap_dp_enabled())
+    if use_work:
+        # model init, flatten(), broadcast_params and the optimizer state were issued on the default stream; the work stream
+        # is non-blocking and does not serialise with it
+        H.work_stream().wait_stream(torch.cuda.current_stream())
+
     def step():
         # with the CU-masked overlap the whole step (input transform included) runs on the non-default work stream
-        ctx = torch.cuda.stream(H.work_stream()) if (H.overlap_enabled() and (world == 1 or H.overlap_dp_enabled())) else contextlib.nullcontext()
+        ctx = torch.cuda.stream(H.work_stream()) if use_work else contextlib.nullcontext()
         with ctx:
             return step_()
 
@@ -264,11 +325,15 @@ def main():
         nbytes = sum(1.0 * (B * a[tidx] * per_bt + 4 * ND * 4 * Hd * Hd) for a, _ in calls)
         secs = sum(ms for _, ms in calls) * 1e-3
         steps_total = sum(a[tidx] for a, _ in calls)
+        # PMC traffic is quoted only when the committed collection was made on THIS workload (tools/collect_profiles.sh stores
+        # the bench line's config.workload in the file); on any other workload it is null, never another shape's number
         traffic, traffic_src = None, None
-        for tname in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        for tname in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
             tpath = os.path.join(ROOT, 'profiles', tname)
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(name, {}).get('hbm_bytes_per_launch')
+                tj = json.load(open(tpath))
+                same = tj.get('_workload', LEGACY_PMC_WORKLOAD) == workload_string(config, args, Dfeat)
+                traffic = tj.get(name, {}).get('hbm_bytes_per_launch') if same else None
                 if traffic is not None:
                     traffic_src = 'profiles/' + tname + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)'
                     break
@@ -289,7 +354,7 @@ def main():
         flop = sum(2.0 * a[4] * a[5] * a[6] * max(1, a[15]) for a, _ in post_summ.get('asr_gemm', []))
         flop += sum(2.0 * a[4] * a[5] * a[6] for a, _ in post_summ.get('asr_gemm16', []))
         gsec = sum(ms for _, ms in gcalls) * 1e-3
-        gemm = {'kernel': 'gemm_kernel (128x128x32 tiles, v_mfma_f32_16x16x32_bf16; %d of %d calls per step on bf16 operands in HBM, the rest fp32 operands converted while staging)' % (n16 // post_steps, len(gcalls) // post_steps),
+        gemm = {'kernel': 'every contraction the host issues: %d of %d calls per step are gemm16_nt / gemm16_tn (128x128x64 tiles, bf16 operands direct to LDS, v_mfma_f32_16x16x32_bf16), the rest gemm_kernel (128x128x32, fp32 operands converted while staging)' % (n16 // post_steps, len(gcalls) // post_steps),
                 'bound': 'mfma', 'achieved': flop / gsec / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
                 'frac': flop / gsec / 1e12 / 2500.0, 'calls_per_step': len(gcalls) / post_steps,
                 'ms_per_step': gsec * 1e3 / post_steps, 'gflop_per_step': flop / post_steps / 1e9,
@@ -304,8 +369,7 @@ def main():
         'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.prec, 'data': 'synthetic',
-        'config': {'workload': 'config/librispeech_asr.yaml (vgg %d, 4xBiLSTM-320, joint CTC-att 0.5), B=%d x T=%d x D=%d per GPU, L=%d, '
-                               '%sdelta+SpecAugment on GPU, fwd+losses+bwd+grad-allreduce+clip+Adadelta, dropout on' % (config['model']['encoder']['vgg'], B, T, Dfeat, L, 'waveform in: GPU fbank + ' if args.waveform else ''),
+        'config': {'workload': workload_string(config, args, Dfeat),
                    'global_batch': B * world, 'frames_per_utt': T, 'parallelism': 'dp%d' % world},
         'valid_frames_per_s': valid / dt, 'loss': loss, 'per_rank_ms_per_step': per_rank_ms,
         'per_rank_frames': [B * T] * world, 'host_enqueue_ms_per_step': t_host / args.steps * 1e3,

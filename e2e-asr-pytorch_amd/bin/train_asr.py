@@ -67,7 +67,9 @@ class Solver(BaseSolver):
         # single-process runs overlap the parameter gradients with the BPTT on CU-masked streams, which serialise against
         # the legacy default stream (src/hipabi.work_stream): the whole loop runs on a non-default stream then
         if (self.dp is None or H.overlap_dp_enabled()) and H.overlap_enabled() and torch.cuda.is_available():
-            with torch.cuda.stream(H.work_stream()):
+            ws = H.work_stream()
+            ws.wait_stream(torch.cuda.current_stream())     # model init / flatten / broadcast / load_ckpt ran on the default stream
+            with torch.cuda.stream(ws):
                 self._exec()
             torch.cuda.current_stream().wait_stream(H.work_stream())
         else:

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "handoff.h"
 #include <stdarg.h>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -66,26 +67,52 @@ extern "C" int asr_stream_destroy(asr_stream_t stream) {
 
 
 // ---- scrubbing a hand-off work area --------------------------------------------------------------------------------
-// Exchange granules are stored L2-locally (`sc0`) by the persistent kernels and can outlive the tensor they were written to:
+// Exchange granules are stored L2-locally (`sc0`) by the persistent kernels and can outlive the launch that wrote them:
 // in the L2 of the XCD that wrote them, and - when such a dirty line is evicted late - in HBM again, on top of a later zero
-// fill.  A work area carved from recycled allocator memory is therefore scrubbed ONCE when it is created: every XCD writes
-// zeros over the whole range with the same L2-local stores (workgroup i covers chunk i / 8; under the dispatcher's round-robin
-// placement each XCD sees every chunk, whatever its starting point), so each L2 holds - and will evict - zeros only.
+// fill.  Hand-off areas therefore live in a pool of their own that never goes back to the tensor allocator
+// (src/hipabi.handoff_acquire), and an area is scrubbed whenever it changes hands: EVERY XCD writes zeros over the whole
+// range with the same L2-local stores, so each L2 holds - and will evict - zeros only.
+// Nothing is assumed about which workgroup runs on which XCD: a workgroup reads its XCC_ID and draws chunk numbers from
+// THAT XCD's ticket counter until the counter has passed the last chunk, so any one workgroup that lands on an XCD covers the
+// whole range for it.  The workgroup that finishes last checks that all eight counters did pass the last chunk; an XCD
+// that received no workgroup at all (never seen; the grid has >= 64 workgroups) sets tickets[15], an abort word the caller
+// registers like those of the persistent launches.
 namespace {
-__global__ __launch_bounds__(256) void scrub_kernel(unsigned long long* base, long n, long chunk) {
-    const long c0 = (long)(blockIdx.x >> 3) * chunk;
-    for (long i = c0 + threadIdx.x; i < c0 + chunk && i < n; i += blockDim.x) st_gran_local(base + i, 0ull);
+__global__ __launch_bounds__(256) void scrub_kernel(unsigned long long* base, long n, long chunk, unsigned nchunk, unsigned* tickets) {
+    __shared__ unsigned s_c;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+    while (true) {
+        if (threadIdx.x == 0) s_c = __hip_atomic_fetch_add(&tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned c = s_c;
+        __syncthreads();
+        if (c >= nchunk) break;                                  // every chunk of this XCD has been handed out
+        const long c0 = (long)c * chunk;
+        for (long i = c0 + threadIdx.x; i < c0 + chunk && i < n; i += blockDim.x) st_gran_local(base + i, 0ull);
+    }
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(&tickets[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (done == gridDim.x) {
+            bool ok = true;
+            for (int x = 0; x < 8; ++x) ok = ok && __hip_atomic_load(&tickets[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nchunk;
+            if (!ok) __hip_atomic_store(&tickets[15], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 }  // namespace
 
-extern "C" int asr_scrub_workspace(void* ptr, size_t bytes, asr_stream_t stream) {
+extern "C" int asr_scrub_workspace(void* ptr, size_t bytes, void* tickets, asr_stream_t stream) {
     ASR_REQUIRE(ptr && ((uintptr_t)ptr & 7) == 0, ASR_E_ARG, "asr_scrub_workspace: null or unaligned pointer");
+    ASR_REQUIRE(tickets && ((uintptr_t)tickets & 3) == 0, ASR_E_ARG, "asr_scrub_workspace: tickets = 64 bytes of device memory owned by the calling stream");
     const long n = (long)(bytes / 8);
     if (n == 0) return ASR_OK;
-    const long chunk = 4096;                                  // granules per workgroup
+    const long chunk = 4096;                                  // granules per ticket
     const long nchunk = (n + chunk - 1) / chunk;
-    ASR_REQUIRE(nchunk * 8 <= 0x7fffffffL, ASR_E_ARG, "asr_scrub_workspace: range too large");
-    hipLaunchKernelGGL(scrub_kernel, dim3((unsigned)(nchunk * 8)), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)ptr, n, chunk);
+    ASR_REQUIRE(nchunk <= 0x3fffffffL, ASR_E_ARG, "asr_scrub_workspace: range too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(tickets, 0, 9 * sizeof(unsigned), st);     // counters + census; the abort word (tickets[15]) is the caller's to clear
+    const long grid = std::max(64L, std::min(8 * nchunk, 1024L));
+    hipLaunchKernelGGL(scrub_kernel, dim3((unsigned)grid), dim3(256), 0, st, (unsigned long long*)ptr, n, chunk, (unsigned)nchunk, (unsigned*)tickets);
     ASR_LAUNCH_CHECK("asr_scrub_workspace");
     return ASR_OK;
 }

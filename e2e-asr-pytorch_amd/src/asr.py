@@ -70,6 +70,8 @@ class Encoder(nn.Module):
 
     def forward(self, input_x, enc_len, ctx=None):
         if self.training and ctx is not None and input_x.is_cuda:
+            # CU split between the recurrence stream and the side stream follows the widest recurrent layer of THIS model
+            H.configure_rec_units([m.dim for m in self.layers if isinstance(m, RNNLayer)])
             F_hip.prepack16([m for m in self.layers if isinstance(m, RNNLayer)], input_x.shape[0], ctx.prec)
         for layer in self.layers:
             input_x, enc_len = layer(input_x, enc_len, ctx)

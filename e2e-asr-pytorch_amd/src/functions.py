@@ -7,6 +7,7 @@ activations.  `anchor` is a dummy requires-grad tensor that keeps autograd calli
 the acoustic features themselves need no gradient.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -35,11 +36,11 @@ class RNNLayerFn(torch.autograd.Function):
         y = _empty((B, T, D), x)
         c = _empty((B, T, ND, Hd), x)
         nbytes = H.lib().asr_lstm_workspace_bytes(B, Hd, ND)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        ws = H.handoff_acquire(nbytes, x.device)          # pool area for this one launch, back to the pool once collected
         H.call('asr_lstm_fwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(layer.b_hh_cat), H.ptr(y), H.ptr(c),
                B, T, Hd, ND, prec, H.ptr(ws), nbytes, st)
         layer.last_ws = ws
-        H.watch_abort(ws)
+        H.watch_abort(ws, release=True)
         yn, stats = y, None
         if layer.layer_norm:
             yn = _empty((B, T, D), x)
@@ -107,13 +108,13 @@ class RNNLayerFn(torch.autograd.Function):
         else:
             dy = dyn
         nbytes = H.lib().asr_lstm_workspace_bytes(B, Hd, ND)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        ws = H.handoff_acquire(nbytes, x.device)
         pre = torch.cuda.Event()
         pre.record(torch.cuda.current_stream())
         H.call('asr_lstm_bwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(dy), H.ptr(c), B, T, Hd, ND, prec,
                H.ptr(ws), nbytes, st)
         layer.last_ws_bwd = ws
-        H.watch_abort(ws)
+        H.watch_abort(ws, release=True)
         H.flush_side(after=pre)       # the upper layer's parameter gradients run beside this recurrence (40 workgroups)
         # gates now holds the gradient wrt the gate pre-activations
         g2 = gates.view(B * T, G)
@@ -210,8 +211,8 @@ def _ws16(layer, B, bwd):
     dev = layer.w_hh_cat.device
     if key not in cache or cache[key][0].device != dev:
         n = int(H.lib().asr_lstm16_workspace_bytes(B, layer.dim, layer.nd, bwd))
-        ws = torch.zeros(n, dtype=torch.uint8, device=dev)
-        H.call('asr_scrub_workspace', H.ptr(ws), ws.numel(), H.stream_ptr())     # see _dec_workspace
+        ws = H.handoff_acquire(n, dev)                    # pool area: scrubbed from every XCD, never returned to the allocator
+        weakref.finalize(layer, H.handoff_release, ws)    # the layer's areas go back to the POOL when the layer dies
         cache[key] = [ws, 0]
     ent = cache[key]
     ent[1] += 1
@@ -281,6 +282,7 @@ class RNNLayerFastFn(torch.autograd.Function):
         y = _empty16((B, T + 2, D), x16)          # rows 0 and T+1 (time pads) are zeroed by the recurrence kernel
         c = _empty((B, T, ND, Hd), x16)
         ws, epoch = _ws16(layer, B, 0)
+        H.abort_guard(ws)
         reserved = 64 if (layer.dp is not None and layer.dp.world > 1) else 0
         H.call('asr_lstm16_fwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(y), H.ptr(c), B, T, Hd, ND,
                H.ptr(ws), ws.numel(), epoch, reserved, st)
@@ -346,6 +348,7 @@ class RNNLayerFastFn(torch.autograd.Function):
         dy = _empty16((B, T, D), x16)
         H.call('asr_dropout_downsample16_bwd', H.ptr(dz), H.ptr(dy), B, T, D, T2, layer.sample_rate, 0, p, seed, st)
         ws, epoch = _ws16(layer, B, 1)
+        H.abort_guard(ws)
         if overlap:
             pre = torch.cuda.Event()
             pre.record(torch.cuda.current_stream())
@@ -588,11 +591,13 @@ def _dec_workspace(model, kind, key, nbytes, device):
     dd = _dec_dims(model, *key)
     k = (kind, tuple(getattr(dd, f) for f, _ in dd._fields_), str(device))
     ws = _DEC_WS.pop(k, None)
-    if ws is None or ws.numel() < nbytes:
+    if ws is not None and ws.numel() < nbytes:
+        H.handoff_release(ws)
+        ws = None
+    if ws is None:
         while len(_DEC_WS) >= 64:                  # variable-length training: keep the 32 most recent shapes (x 2 passes)
-            _DEC_WS.pop(next(iter(_DEC_WS)))
-        ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
-        H.call('asr_scrub_workspace', H.ptr(ws), ws.numel(), H.stream_ptr())     # every XCD's L2 view of the recycled block
+            H.handoff_release(_DEC_WS.pop(next(iter(_DEC_WS))))      # evicted areas go back to the hand-off POOL, not to the allocator
+        ws = H.handoff_acquire(nbytes, device)     # zeroed + scrubbed from every XCD whenever an area changes hands
     _DEC_WS[k] = ws                                # most recently used last
     return ws
 
@@ -606,7 +611,7 @@ def att_decoder_forward(model, enc, enc_len, L, teacher, prec):
         nwork = int(H.lib().asr_att_decoder_fwd_work_bytes(ctypes.byref(d)))     # 0: no single-launch plan for this shape
         if nwork:
             st['work'] = _dec_workspace(model, 'fwd', (d.B, d.Tp, d.L), nwork, enc.device)
-            H.watch_abort(st['work'])
+            H.abort_guard(st['work'])
     w = H.dec_weights_struct(_dec_tensors(model, False), d.NL)
     s = H.dec_state_struct(st)
     t_ptr, t_ld = (None, 0)
@@ -616,6 +621,7 @@ def att_decoder_forward(model, enc, enc_len, L, teacher, prec):
         t_ptr, t_ld = H.ptr(teacher), teacher.shape[1]
     H.call('asr_att_decoder_fwd', ctypes.byref(d), ctypes.byref(w), H.ptr(enc), H.ptr(enc_len), t_ptr, t_ld,
            ctypes.byref(s), prec, H.stream_ptr())
+    H.watch_abort(st.get('work'))
     return d, st
 
 
@@ -647,13 +653,17 @@ class AttDecoderFn(torch.autograd.Function):
         nbytes = H.lib().asr_att_decoder_bwd_workspace_bytes(ctypes.byref(d))
         ws = _dec_workspace(model, 'bwd', (d.B, d.Tp, d.L), nbytes, enc.device)
         model._last_dec_bwd_ws = ws          # kept for diagnostics (tools/diag_dec.py)
-        if int(H.lib().asr_att_decoder_bwd_persistent_tiles(ctypes.byref(d))) > 0:
-            H.watch_abort(ws, int(H.lib().asr_att_decoder_bwd_status_offset(ctypes.byref(d))))
+        persistent = int(H.lib().asr_att_decoder_bwd_persistent_tiles(ctypes.byref(d))) > 0
+        status_off = int(H.lib().asr_att_decoder_bwd_status_offset(ctypes.byref(d))) if persistent else 0
+        if persistent:
+            H.abort_guard(ws, status_off)
         overlap = H.overlap_enabled() and (getattr(model, '_dp', None) is None or H.overlap_dp_enabled())
         looped = ctypes.c_int(0)
         H.call('asr_att_decoder_bwd_ex', ctypes.byref(d), ctypes.byref(w), ctypes.byref(g), H.ptr(enc), H.ptr(enc_len),
                ctypes.byref(s), H.ptr(dlogits), H.ptr(denc), H.ptr(ws), nbytes, prec, 1 if overlap else 0, ctypes.byref(looped),
                H.stream_ptr())
+        if persistent:
+            H.watch_abort(ws, status_off)
         if overlap:
             # the decoder's parameter gradients (15 launches, ~0.7 ms) are off the path to the encoder gradient: they run on the
             # CU-masked side stream beside the encoder's BPTT (issued at its first recurrence, RNNLayerFastFn.backward)

@@ -433,9 +433,11 @@ int asr_debug_occupy(int workgroups, int lds_bytes, double seconds, asr_stream_t
  * starting at per-XCD unit `first` (0..31).  Mask layout measured on MI355X (tools/probe/cumask.hip): mask bit i = XCD i % 8,
  * unit i / 8 of that XCD (shader engine (i / 8) % 4); a mask that leaves an XCD empty is ignored by the driver.
  * (No reference counterpart: the reference trains on one CUDA stream.) */
-/* Zero a hand-off work area from EVERY XCD with L2-local stores (once, when the caller creates it from allocator memory): see
- * csrc/core.hip.  No reference counterpart. */
-int asr_scrub_workspace(void* ptr, size_t bytes, asr_stream_t stream);
+/* Zero a hand-off work area from EVERY XCD with L2-local stores (whenever an area of the caller's hand-off pool changes hands):
+ * see csrc/core.hip.  `tickets`: 64 bytes of device memory private to the calling stream (per-XCD chunk counters, cleared
+ * by the call; word 15 is set when an XCD received no workgroup - register it like an abort word).  Placement-independent:
+ * workgroups draw chunks from the counter of the XCD they find themselves on.  No reference counterpart. */
+int asr_scrub_workspace(void* ptr, size_t bytes, void* tickets, asr_stream_t stream);
 int asr_stream_create_cu_mask(int first, int count, asr_stream_t* stream);
 int asr_stream_destroy(asr_stream_t stream);
 

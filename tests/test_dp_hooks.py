@@ -99,12 +99,13 @@ def test_bucket_hooks_inside_backward(prec, overlap_dp, monkeypatch):
     covered = sum(b - a for a, b in dp.buckets)
     assert covered == model.flat_grad.numel()
     # the reduced buffer holds the SUM over two identical replicas; same clip decision and update as one process
-    # fp32 mode: equal up to the order of the split reductions.  bf16 mode: two MODEL INSTANCES are compared here, and the
-    # persistent decoder forward was seen to differ between instances by up to 2e-2 on single logits on one box (within
-    # the bf16 parity tolerance; tracked in DESIGN.md "open issues"), so the bound is the bf16 gradient tolerance
+    # both modes: equal up to the order of the split reductions (fp32 atomics).  Two MODEL INSTANCES are compared here; round 2
+    # excused a 2e-2 deviation of single decoder logits between instances in bf16 mode - that was the polling defect of
+    # csrc/handoff.h, fixed there and pinned by tests/test_handoff_isa.py, so the excuse is gone
     rel = float((model.flat_grad - 2.0 * g_ref).norm() / (2.0 * g_ref).norm())
-    assert rel < (1e-5 if prec == 'fp32' else 2e-2), rel
+    assert rel < (1e-5 if prec == 'fp32' else 1e-4), rel
+    assert abs(float(out['total_loss']) - float(out_r['total_loss'])) < 1e-6 * max(1.0, abs(float(out_r['total_loss'])))
     n_dp, n_ref = float(out['grad_normsq'].sqrt()) * 0.5, float(out_r['grad_normsq'].sqrt())
-    assert abs(n_dp - n_ref) < (1e-4 if prec == 'fp32' else 2e-2) * n_ref
+    assert abs(n_dp - n_ref) < 1e-4 * n_ref
     drel = float((model.flat_param - ref.flat_param).norm() / (ref.flat_param.norm() + 1e-30))
-    assert drel < (1e-6 if prec == 'fp32' else 1e-3), drel
+    assert drel < (1e-6 if prec == 'fp32' else 1e-5), drel

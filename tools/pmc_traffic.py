@@ -3,7 +3,10 @@ per-launch HBM traffic record profiles/rNN_pmc_traffic.json that bench.py report
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o x -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch/x_counter_collection.csv gpurun_out/pmc_write/x_counter_collection.csv profiles/rNN_pmc_traffic.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch/x_counter_collection.csv gpurun_out/pmc_write/x_counter_collection.csv profiles/rNN_pmc_traffic.json [bench.json]
+
+The optional fourth argument is the bench JSON line of the SAME command: its config.workload is stored as `_workload`, and
+bench.py quotes roofline.traffic from the file only on that workload.
 
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are KiB; FETCH_SIZE
 tallies 128-byte requests at 64 bytes, so it is doubled; WRITE_SIZE is exact."""
@@ -27,6 +30,10 @@ def per_kernel(path, counter):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    workload = None
+    if len(sys.argv) > 4:
+        lines = [l for l in open(sys.argv[4]).read().splitlines() if l.startswith('{')]
+        workload = json.loads(lines[-1])['config']['workload']
     f, w = per_kernel(fetch, 'FETCH_SIZE'), per_kernel(write, 'WRITE_SIZE')
     rec = {}
     for k in sorted(set(f) | set(w)):
@@ -36,6 +43,8 @@ def main():
         wa = sw / nw if nw else 0.0
         rec[k] = {'launches': max(nf, nw), 'FETCH_SIZE_KiB_avg': fa, 'WRITE_SIZE_KiB_avg': wa,
                   'hbm_bytes_per_launch': (2.0 * fa + wa) * 1024.0, 'hbm_bytes_per_launch_uncorrected': (fa + wa) * 1024.0}
+    if workload is not None:
+        rec['_workload'] = workload
     json.dump(rec, open(out, 'w'), indent=1)
     print(json.dumps(rec, indent=1))
 

@@ -1,13 +1,12 @@
 #!/bin/bash
 # kernel trace of the bench step with the CU-masked overlap off / on (gpurun_out/<tag>/): phase lengths per step.
-# rocprofv3 may crash in its finaliser with CU-masked streams alive - the trace files are complete by then.
 TAG=${1:-ovl}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 for mode in 0 1; do
 export ASR_OVERLAP=$mode
-rocprofv3 --kernel-trace --output-format csv -d $OUT/prof$mode -o x -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/prof_bench$mode.json 2> $OUT/prof$mode.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof$mode -o x -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/prof_bench$mode.json 2> $OUT/prof$mode.err || { echo "rocprofv3 exited $?"; exit 1; }
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open('$OUT/prof$mode/x_kernel_trace.csv')))

@@ -1116,9 +1116,10 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t dec_bwd_persist_work_bytes_fw(const asr_dec_dims_t& d);
 int dec_bwd_persist_tiles_fw(const asr_dec_dims_t& d);
+int dec_bwd_persist_tiles_max_fw(const asr_dec_dims_t& d);
 struct BwdLayout {
     size_t dhs, dxin, dq, dkey, datt_next, dcf, wq_t, slots, wslots, dkeypre, wcat[ASR_MAX_DEC_LAYERS], pwork, pwork_bytes, total;
-    int ntp;                // tiles per utterance of the persistent backward (0: no plan)
+    int ntp, ntp_max;       // tiles per utterance of the persistent backward under the current plan preference (0: no plan) / the larger of its two plans
     int nte, slot;          // energy-backward tiles per utterance, floats per slot
     int TE, NG;             // frames per energy-backward workgroup, frame groups
     int TC;                 // outputs per conv-backward workgroup
@@ -1174,7 +1175,8 @@ BwdLayout bwd_layout(const asr_dec_dims_t& d) {
     o.dcf = take((size_t)d.NL * d.B * d.Dd);
     o.wq_t = take((size_t)d.Q * d.A);
     o.ntp = dec_bwd_persist_tiles_fw(d);
-    o.slots = take((size_t)d.B * (o.nte > o.ntp ? o.nte : o.ntp) * o.slot);
+    o.ntp_max = dec_bwd_persist_tiles_max_fw(d);
+    o.slots = take((size_t)d.B * (o.nte > o.ntp_max ? o.nte : o.ntp_max) * o.slot);
     o.pwork_bytes = dec_bwd_persist_work_bytes_fw(d);
     o.pwork = take(o.pwork_bytes / sizeof(float) + 64);
     o.wslots = take((size_t)d.B * o.nch * d.Kn * taps);
@@ -1239,15 +1241,21 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
 
 size_t dec_bwd_persist_work_bytes(const asr_dec_dims_t& d);
 int dec_bwd_persist_tiles(const asr_dec_dims_t& d);
+int dec_bwd_persist_tiles_max(const asr_dec_dims_t& d);
+int dec_bwd_plan_kind(const asr_dec_dims_t& d);
 namespace { size_t dec_bwd_persist_work_bytes_fw(const asr_dec_dims_t& d) { return dec_bwd_persist_work_bytes(d); }
-            int dec_bwd_persist_tiles_fw(const asr_dec_dims_t& d) { return dec_bwd_persist_tiles(d); } }
+            int dec_bwd_persist_tiles_fw(const asr_dec_dims_t& d) { return dec_bwd_persist_tiles(d); }
+            int dec_bwd_persist_tiles_max_fw(const asr_dec_dims_t& d) { return dec_bwd_persist_tiles_max(d); } }
 int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const int64_t* enc_len,
                        const float* dhs, float* dxin, float* dq, float* dkey, float* slots, int slot, const float* wcatT, const float* wqT,
                        void* work, size_t work_bytes, float** dgates_out, hipStream_t st);
 
+int dec_fwd_plan_kind(const asr_dec_dims_t& d);
 extern "C" size_t asr_att_decoder_fwd_work_bytes(const asr_dec_dims_t* dims) {
     return dims ? dec_fwd_persist_work_bytes(*dims) : 0;
 }
+extern "C" int asr_att_decoder_fwd_plan(const asr_dec_dims_t* dims) { return dims ? dec_fwd_plan_kind(*dims) : 0; }
+extern "C" int asr_att_decoder_bwd_plan(const asr_dec_dims_t* dims) { return dims ? dec_bwd_plan_kind(*dims) : 0; }
 
 extern "C" int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* weights,
                                    const float* enc, const int64_t* enc_len, const int64_t* teacher, int teacher_ld,
@@ -1429,7 +1437,7 @@ extern "C" int asr_att_decoder_bwd_ex(const asr_dec_dims_t* dims, const asr_dec_
     hipMemsetAsync(p.dhs, 0, sizeof(float) * (size_t)BL * SW, st);
     hipMemsetAsync(p.dkey, 0, sizeof(float) * (size_t)d.B * d.Tp * d.A, st);
     hipMemsetAsync(p.dq, 0, sizeof(float) * (size_t)BL * d.A, st);
-    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * (lay.nte > lay.ntp ? lay.nte : lay.ntp) * lay.slot, st);
+    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * (lay.nte > lay.ntp_max ? lay.nte : lay.ntp_max) * lay.slot, st);
 
     // transposed weights so that every per-step contraction is K-contiguous
     for (int l = 0; l < d.NL; ++l) {

@@ -20,135 +20,31 @@
 // the polled data is handed over.
 #include "common.h"
 #include "handoff.h"
-#include <unordered_map>
 #include <stdlib.h>
 #include <algorithm>
 
 static int g_persist_fwd = -1, g_persist_bwd = -1;   // -1: from env ASR_DEC_PERSIST / ASR_DEC_PERSIST_BWD (default on)
-// bit 0: persistent forward, bit 1: persistent backward; returns the previous setting
+static int g_stream_fwd = -1, g_stream_bwd = -1;     // 1: take the streamed-tile plan (decoder_stream.hip) even where the LDS-resident one exists; -1: env ASR_DEC_STREAM
+// bit 0: persistent forward, bit 1: persistent backward, bit 2 / 3: prefer the streamed-tile plan forward / backward (tests, A/B
+// runs; shapes without an LDS-resident plan take the streamed one anyway); returns the previous setting
 extern "C" int asr_att_decoder_set_persistent(int flags) {
-    const int old = (g_persist_fwd != 0 ? 1 : 0) | (g_persist_bwd != 0 ? 2 : 0);
-    g_persist_fwd = flags & 1; g_persist_bwd = (flags >> 1) & 1;
+    const int old = (g_persist_fwd != 0 ? 1 : 0) | (g_persist_bwd != 0 ? 2 : 0) | (g_stream_fwd > 0 ? 4 : 0) | (g_stream_bwd > 0 ? 8 : 0);
+    g_persist_fwd = flags & 1; g_persist_bwd = (flags >> 1) & 1; g_stream_fwd = (flags >> 2) & 1; g_stream_bwd = (flags >> 3) & 1;
     return old;
 }
+static void stream_env() {
+    if (g_stream_fwd < 0) { const char* e = getenv("ASR_DEC_STREAM"); g_stream_fwd = (e && e[0] == '1') ? 1 : 0; }
+    if (g_stream_bwd < 0) { const char* e = getenv("ASR_DEC_STREAM"); g_stream_bwd = (e && e[0] == '1') ? 1 : 0; }
+}
+// decoder_stream.hip
+size_t dec_fwd_stream_work_bytes(const asr_dec_dims_t& d);
+int dec_fwd_streamed(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const float* enc,
+                     const int64_t* enc_len, void* work, size_t work_bytes, hipStream_t st);
+
+#include "decoder_cluster.h"
+#include "decoder_bwd_common.h"
 
 namespace {
-
-// Tag = 6 bits in the three mantissa LSBs of both floats of a granule: 2-bit step sequence + 4-bit launch epoch.  (With a
-// 2-bit tag any stale or foreign 8 bytes pass the check with probability 1/4; recycled allocator memory whose old lines
-// still sit in this XCD's L2 did exactly that in the first step of a launch.)  Payload loses 3 of 24 mantissa bits.
-constexpr u64 PAIR_MASK = 7ull | (7ull << 32);
-__device__ __forceinline__ u64 pair_want(unsigned seq, unsigned epoch) {
-    // the epoch field takes the values 2..15 only: then BOTH words of a granule carry non-zero tag bits (low: seq != 0, high:
-    // epoch >> 1 != 0).  With epoch 0 / 1 the high word's tag was 0, and any 8 bytes whose second word ends in three zero bits
-    // and whose first word ends in the step tag passed - an int64 token id or length (5 = 0x0000000000000005) is exactly a
-    // valid "zero payload" granule of (epoch 1, first step).  Seen on first launches (epoch 1) on memory recycled from such
-    // tensors: whole records accepted as zeros, attention rows of 1e30.
-    epoch = 2u + epoch % 14u;
-    const unsigned tag = ((epoch & 15u) << 2) | seq;
-    return (u64)(tag & 7u) | ((u64)(tag >> 3) << 32);
-}
-__device__ __forceinline__ u64 pack2(float a, float b, u64 want) {
-    return ((u64)(__float_as_uint(a) & ~7u) | ((u64)(__float_as_uint(b) & ~7u) << 32)) | want;
-}
-__device__ __forceinline__ float lo_f(u64 g) { return __uint_as_float((unsigned)g & ~7u); }
-__device__ __forceinline__ float hi_f(u64 g) { return __uint_as_float((unsigned)(g >> 32) & ~7u); }
-constexpr float NEG_BIG = -1e30f;       // masked energy in the exchange records (-inf would turn into NaN under the tag bit)
-constexpr int NCW = 8, NPW = 4;         // compute waves, polling waves
-constexpr int FSW_NU = 3;               // 16-column units of the forward energy sweep per compute wave (A <= 384)
-constexpr int FCVX_LD = 32;             // row of the split-bf16 conv tile = the K slots of one MFMA
-#ifdef ASR_DIAG
-#define DP_DECL unsigned long long dg_t = __builtin_amdgcn_s_memrealtime(), dg_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define DP_MARK(k) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); dg_acc[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); }
-#define DP_DUMP { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long* o = (unsigned long long*)p.status + 128; for (int k = 0; k < 16; ++k) o[k] = dg_acc[k]; } }
-#define DP_JIT(k)
-#elif defined(ASR_JITTER)
-// Race-detector build (`make jitter`, tools/jitter_dec.py): every phase boundary of both roles sleeps for a pseudo-random time
-// that depends on (workgroup, wave, step, boundary, launch epoch), so each launch runs under a different interleaving of its
-// waves and workgroups.  A result that changes with the jitter is an ordering bug (a missing barrier, a slot reused too early).
-__device__ __forceinline__ void dp_jitter(unsigned k, unsigned step, unsigned epoch) {
-    unsigned h = (blockIdx.x * 0x9E3779B1u) ^ ((threadIdx.x >> 6) * 0x85EBCA6Bu) ^ (k * 0xC2B2AE35u) ^ (step * 0x27D4EB2Fu) ^ (epoch * 0x165667B1u);
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-    h = __builtin_amdgcn_readfirstlane(h);
-    if ((h & 3u) == 0u) {                                  // one boundary in four: up to ~8 us
-        const unsigned n = (h >> 2) & 63u;
-        for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
-    }
-}
-#define DP_DECL
-#define DP_MARK(k) dp_jitter(k, (unsigned)t, p.epoch);
-#define DP_JIT(k) dp_jitter(32 + k, (unsigned)t, p.epoch);
-#define DP_DUMP
-#else
-#define DP_DECL
-#define DP_MARK(k)
-#define DP_JIT(k)
-#define DP_DUMP
-#endif
-constexpr int RB = 5;                   // gate rows per batch of the cell contraction
-inline size_t align_up256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-__device__ __forceinline__ float bf2f_(unsigned short x) { return __uint_as_float((unsigned)x << 16); }
-__device__ __forceinline__ float tanh_f(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
-
-// wave-wide sum on the DPP path (quad swaps, mirrors, row broadcasts: 6 VALU steps, no LDS permutes); uniform result
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-#define DPB_STEP(CTRL, RMASK) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false));
-    DPB_STEP(0xB1, 0xf)      // quad_perm [1,0,3,2]
-    DPB_STEP(0x4E, 0xf)      // quad_perm [2,3,0,1]
-    DPB_STEP(0x141, 0xf)     // row_half_mirror
-    DPB_STEP(0x140, 0xf)     // row_mirror
-    DPB_STEP(0x142, 0xa)     // row_bcast15 -> rows 1, 3
-    DPB_STEP(0x143, 0xc)     // row_bcast31 -> rows 2, 3
-#undef DPB_STEP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-// sum over aligned groups of 8 lanes (every lane of the group gets it): quad swaps + half-row mirror, no LDS permutes
-__device__ __forceinline__ float sum8_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
-    return v;
-}
-__device__ __forceinline__ float wave_max_dpp(float v) {
-#define DPB_STEP(CTRL, RMASK) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false)));
-    DPB_STEP(0xB1, 0xf)
-    DPB_STEP(0x4E, 0xf)
-    DPB_STEP(0x141, 0xf)
-    DPB_STEP(0x140, 0xf)
-    DPB_STEP(0x142, 0xa)
-    DPB_STEP(0x143, 0xc)
-#undef DPB_STEP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-struct PD {
-    asr_dec_dims_t d;
-    asr_dec_weights_t w;
-    asr_dec_state_t s;
-    const float* enc;
-    const int64_t* enc_len;
-    const unsigned short* wcat16;   // (4Dd, KCP) bf16 rows [W_ih[:, Dd:Dd+E] | W_hh | 0-pad]
-    const float* embproj;           // (B*L, 4Dd)  W_ih[:, :Dd] . emb(token)
-    u64* xbuf;
-    unsigned* status;
-    int NT, TE, UPW, QPW, CPW;      // tiles per utterance, frames per tile, hidden units / query outputs / context columns per workgroup
-    int HG2, QG2, SG2;              // granules per producer record (even)
-    int KC, KCP;                    // E + Dd, padded to a multiple of 8
-    int allow_local;
-    unsigned epoch;                 // launch counter (tag bits)
-};
-
-// barrier among the NCW compute waves only (the polling waves are inside a spin loop at these points)
-__device__ __forceinline__ void compute_barrier(unsigned* cnt, unsigned& gen) {
-    gen += NCW;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 template <int KNMAX, int TPW>
 __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
@@ -163,6 +59,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
     const int cb = slot / p.NT, j = slot - cb * p.NT;
     const int b = cb * 8 + xcd;
     if (b >= d.B) return;
+    const unsigned epoch_ = __builtin_amdgcn_readfirstlane(p.status[EPOCH_WORD]);     // launch epoch of this work area (decoder_cluster.h)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = p.NT, A = d.A, E = d.E, Dd = d.Dd, Tp = d.Tp, Kn = d.Kn, Ks = d.Ks, L = d.L;
     const int taps = 2 * Ks + 1, XW = Dd + E;
@@ -229,7 +126,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             // H: h_{t-1} of the utterance -> s_x[E ..]
             if (t > 0) {
                 const u64* src = xb((t - 1) & 1);
-                const u64 want = pair_want(seq_of(t - 1), p.epoch);
+                const u64 want = pair_want(seq_of(t - 1), epoch_);
                 for (int i0 = gt; 2 * i0 < NT * p.HG2; i0 += np) {
                     u64 lo[1], hi[1];
                     gather16<1>(src + 2 * i0, 0, 1, PAIR_MASK, want, lo, hi, p.status);
@@ -247,7 +144,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             // Q: query of step t -> s_q
             {
                 const u64* src = xb(t & 1) + (long)NT * p.HG2;
-                const u64 want = pair_want(seq_of(t), p.epoch);
+                const u64 want = pair_want(seq_of(t), epoch_);
                 for (int i0 = gt; 2 * i0 < NT * p.QG2; i0 += np) {
                     u64 lo[1], hi[1];
                     gather16<1>(src + 2 * i0, 0, 1, PAIR_MASK, want, lo, hi, p.status);
@@ -265,7 +162,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             // S: softmax records of all tiles -> s_stage (flat copy)
             {
                 const u64* src = xb(t & 1) + (long)NT * (p.HG2 + p.QG2);
-                const u64 want = pair_want(seq_of(t), p.epoch);
+                const u64 want = pair_want(seq_of(t), epoch_);
                 const int npair = NT * p.SG2 / 2;
                 for (int i0 = gt; i0 < npair; i0 += 10 * np) {
                     u64 lo[10], hi[10];
@@ -341,7 +238,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
         const int lane = lz_;
         const long row = (long)b * L + t;
         float* s_x = s_x2 + (t & 1) * p.KCP;
-        const u64 want = pair_want(seq_of(t), p.epoch);
+        const u64 want = pair_want(seq_of(t), epoch_);
         u64* out = xb(t & 1);
         // operands of the cell phase that do not depend on this step's hand-offs: requested now
         float add_r = 0.f;                                              // lane r of the wave: embproj + both biases of its gate row
@@ -646,42 +543,6 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
     DP_DUMP
 }
 
-__global__ void build_wcat16_kernel(const float* __restrict__ wih, const float* __restrict__ whh, unsigned short* __restrict__ out,
-                                    int rows, int Dd, int E, int KCP) {
-    const long total = (long)rows * KCP;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / KCP), k = (int)(i - (long)r * KCP);
-        float v = 0.f;
-        if (k < E) v = wih[(long)r * (Dd + E) + Dd + k];
-        else if (k < E + Dd) v = whh[(long)r * Dd + (k - E)];
-        out[i] = f2bf_bits(v);
-    }
-}
-
-// Every workgroup of a cluster waits for its peers, so the whole grid has to be resident at once: checked, not assumed
-// (occupancy of THIS kernel at its block size and LDS x compute units; the API can over-report, so at most one workgroup per
-// CU is counted - each one needs most of a CU's LDS anyway).  Not resident -> the caller falls back to the per-step kernels.
-template <typename K>
-bool grid_resident(K kernel, int grid, int block, size_t lds) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) return false;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return grid <= cus;
-}
-
-// Launch epoch (4 tag bits) PER WORK AREA: consecutive launches on the same address range carry consecutive epochs, so the tags a
-// slot can still hold - those of the previous launch on that range - never match, and a tag recurs only after 16 launches that
-// each rewrote every slot.  (A process-wide counter let two consecutive users of one range be exactly 16 launches apart when
-// other shapes ran in between.)  Callers keep a work area per shape for the life of the process (src/functions._dec_workspace).
-// Host-side state, not thread-safe: one launching thread per process, like the rest of the library's launch path.
-inline unsigned next_epoch(const void* work, unsigned first) {
-    static std::unordered_map<const void*, unsigned> epochs;
-    auto it = epochs.find(work);
-    if (it == epochs.end()) it = epochs.emplace(work, first).first;
-    return it->second++;
-}
-
 struct PersistPlan { bool ok; int tpw, NT, TE, UPW, QPW, CPW, HG2, QG2, SG2, KC, KCP; size_t lds, status_bytes, xbuf_bytes, wcat_bytes, emb_bytes, total; };
 
 PersistPlan persist_plan(const asr_dec_dims_t& d) {
@@ -721,23 +582,32 @@ PersistPlan persist_plan(const asr_dec_dims_t& d) {
 
 }  // namespace
 
-size_t dec_fwd_persist_work_bytes(const asr_dec_dims_t& d) {
+// 0: per-step kernels, 1: LDS-resident tiles (this file), 2: streamed tiles (decoder_stream.hip)
+int dec_fwd_plan_kind(const asr_dec_dims_t& d) {
+    stream_env();
     const PersistPlan pl = persist_plan(d);
-    return pl.ok ? pl.total : 0;
+    if (pl.ok && !g_stream_fwd) return 1;
+    return dec_fwd_stream_work_bytes(d) ? 2 : (pl.ok ? 1 : 0);
+}
+size_t dec_fwd_persist_work_bytes(const asr_dec_dims_t& d) {
+    const PersistPlan pl = persist_plan(d);                 // sized for whichever plan may be taken (the preference can be switched)
+    return std::max(pl.ok ? pl.total : (size_t)0, dec_fwd_stream_work_bytes(d));
 }
 
 // Returns ASR_OK when the whole loop was launched, 1 when the configuration has no persistent plan, negative on error.
 int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const float* enc,
                        const int64_t* enc_len, void* work, size_t work_bytes, hipStream_t st) {
     if (g_persist_fwd < 0) { const char* e = getenv("ASR_DEC_PERSIST"); g_persist_fwd = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_persist_fwd) return 1;
+    if (dec_fwd_plan_kind(d) == 2) return dec_fwd_streamed(d, w, s, enc, enc_len, work, work_bytes, st);
     const PersistPlan pl = persist_plan(d);
-    if (!g_persist_fwd || !pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv) return 1;
+    if (!pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv) return 1;
     char* base = (char*)work;
     unsigned* status = (unsigned*)base;
     u64* xbuf = (u64*)(base + pl.status_bytes);
     unsigned short* wcat16 = (unsigned short*)(base + pl.status_bytes + pl.xbuf_bytes);
     float* embproj = (float*)(base + pl.status_bytes + pl.xbuf_bytes + pl.wcat_bytes);
-    hipMemsetAsync(work, 0, pl.status_bytes + pl.xbuf_bytes, st);
+    clear_work(work, pl.xbuf_bytes, st);
     hipLaunchKernelGGL(build_wcat16_kernel, dim3(512), dim3(256), 0, st, w.Wih[0], w.Whh[0], wcat16, 4 * d.Dd, d.Dd, d.E, pl.KCP);
     const int XW = d.Dd + d.E;
     int rc = asr_gemm(s.xin, w.Wih[0], embproj, nullptr, d.B * d.L, 4 * d.Dd, d.Dd, XW, XW, 4 * d.Dd, 1, 1, ASR_ACT_NONE, 0, 1, 1, 0, 0, 0,
@@ -745,15 +615,15 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
     if (rc != ASR_OK) return rc;
     static int allow = -1;
     if (allow < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); allow = (e && e[0] == '0') ? 0 : 1; }
-    PD p{d, w, s, enc, enc_len, wcat16, embproj, xbuf, status, pl.NT, pl.TE, pl.UPW, pl.QPW, pl.CPW, pl.HG2, pl.QG2, pl.SG2, pl.KC, pl.KCP, allow, next_epoch(work, 1u)};
+    PD p{d, w, s, enc, enc_len, wcat16, embproj, xbuf, status, pl.NT, pl.TE, pl.UPW, pl.QPW, pl.CPW, pl.HG2, pl.QG2, pl.SG2, pl.KC, pl.KCP, allow};
     const int cpx = cdiv(d.B, 8);
     const dim3 grid(8 * cpx * pl.NT), block(64 * (NCW + NPW));
 #define DPF_LAUNCH(KN_, TPW_)                                                                                                   \
     {                                                                                                                           \
-        static bool attr = false;                                                                                               \
-        if (!attr) { hipFuncSetAttribute((const void*)dec_fwd_persist<KN_, TPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr = true; } \
+        hipFuncSetAttribute((const void*)dec_fwd_persist<KN_, TPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); /* per device, every call: no process-wide flag */ \
         if (!grid_resident(dec_fwd_persist<KN_, TPW_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                              \
         hipLaunchKernelGGL((dec_fwd_persist<KN_, TPW_>), grid, block, pl.lds, st, p);                                             \
+        hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                   \
     }
     if (d.Kn <= 4) {
         if (pl.tpw == 2) DPF_LAUNCH(4, 2) else if (pl.tpw == 4) DPF_LAUNCH(4, 4) else if (pl.tpw == 5) DPF_LAUNCH(4, 5) else DPF_LAUNCH(4, 8)
@@ -783,292 +653,7 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
 // =================================================================================================
 namespace {
 
-constexpr int NPB = 3;            // polling waves of the backward kernel
-constexpr int RCB = 8, RPB = 9;   // rows of the transposed-weight product per compute wave / per polling wave
-constexpr int RPWB = 12;          // (s_out is sized for RPWB * 8 >= RCB * ncw + RPB * NPB outputs)
-constexpr int KCHB = 5;           // 4-column chunks of the gate-gradient vector per lane (4*Dd <= 1280)
-constexpr int UQW = 4;            // hidden units per compute wave in the query-part product
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
-__device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_, a), __builtin_bit_cast(bf16x2_, b), c, false);
-}
-
-struct PB {
-    asr_dec_dims_t d;
-    asr_dec_weights_t w;
-    asr_dec_state_t s;
-    const unsigned short* enc16;
-    const int64_t* enc_len;
-    const float* dhs;               // (B,L,Dd) gradient wrt h_t from the output layer
-    float* dxin;                    // (B,L,Dd+E)  context part written here
-    float* dq;                      // (B,L,A)     gradient wrt the query pre-activation
-    float* dkey;                    // (B,T',A)    zero on entry, accumulated atomically
-    float* slots;                   // (B*NT, slot)  d w_g [a], d W_proj [k][a], d b_g
-    float* dgates;                  // (B,L,4Dd)   gate pre-activation gradients (the saved gates stay intact)
-    const unsigned short* wcatT16;  // (Dd+E+Dd rows = input columns) x R4 bf16, row x = gradient weights of input column x
-    const float* wqT;               // (Dd x A)
-    u64* xbuf;
-    unsigned* status;
-    int slot, NT, TE, UPW, CPW, R4;
-    int CG2, QG2, VG2, NG2;         // granules per producer record (even)
-    int allow_local;
-    unsigned epoch;
-    int poll_delay;                 // s_sleep units before the Q/V polling starts
-};
-
-// LDS carve of dec_bwd_persist, shared by the kernel and the host plan (float offsets follow the bf16 arrays).
-struct BCarve { int AP, DW, PADL, WT, AQ, key, dl, wp16, dg16, wq16, cvx, cvT, shorts; int wc, crec, qst, nrec, dcp, de, out, hq, pt, dcx, dq, floats; };
-constexpr int SW_MT = 3;          // 16-frame tiles of the sweep (TE <= 40: the third one is ragged)
-constexpr int SW_NU = 3;          // 16-column units of the sweep per compute wave (A <= 320 over ncw + 3 waves)
-constexpr int SW_NUP = 2;         //   and per polling wave (unit u -> wave u % (ncw + 3): wave index >= ncw gets at most two)
-constexpr int CVX_LD = 32;        // row of the split-bf16 conv tile = the K slots of one MFMA
-constexpr int CVT_LD = 16 * SW_MT + 8;
-__host__ __device__ inline BCarve bwd_carve(int TE, int KP, int A, int E, int Kn, int Ks, int NT, int UPW, int CG2, int QG2, int NG2) {
-    BCarve c;
-    int ap8 = 8 * ((A + 63) / 64); if ((ap8 & 1) == 0) ++ap8;
-    c.AP = 8 * ap8;                                     // row stride of the [frame][a] tiles: >= 64*ceil(A/64), odd in 16-byte units
-    c.PADL = Ks + 8 + ((4 - ((2 * Ks) & 3)) & 3);       // left zero pad of a dconv row: PADL + Ks is a multiple of 4
-    c.DW = (c.PADL + NT * TE + Ks + 8 + 3) & ~3;        // zero-padded dconv row,
-    if (((c.DW >> 2) & 1) == 0) c.DW += 4;              //   an odd number of 16-byte units (bank spread across the Kn rows)
-    c.WT = (2 * Ks + 1 + 3) & ~3;                       // zero-padded filter row
-    int o = 0;
-    c.key = o; o += (TE * A + 7) & ~7;
-    c.dl = o; o += TE * c.AP;
-    c.wp16 = o; o += 16 * c.AP;
-    c.dg16 = o; o += 64 * KCHB * 4;
-    c.AQ = 64 * ((A + 63) / 64);                        // row of the resident W_q^T slice
-    c.wq16 = o; o += ((UPW + 1) & ~1) * c.AQ;
-    c.cvx = o; o += 16 * SW_MT * CVX_LD;                // [48][32] conv tile of the step, {hi, lo, hi} slots
-    c.cvT = o; o += 16 * CVT_LD;                        // [16][56] the same tile transposed (hi only)
-    c.shorts = o;
-    o = 0;
-    c.wc = o; o += Kn * c.WT;
-    c.crec = o; o += NT * CG2 * 2;
-    c.qst = o; o += NT * QG2 * 2;
-    c.nrec = o; o += NT * NG2 * 2 + 8;
-    c.dcp = o; o += Kn * c.DW;
-    c.de = o; o += 16 * SW_MT;                          // [48], rows >= TE stay 0
-    c.out = o; o += RPWB * 8;
-    c.hq = o; o += 64;
-    c.pt = o; o += 4 * Kn * TE;
-    c.dcx = o; o += (E + 3) & ~3;
-    c.dq = o; o += (A + 3) & ~3;
-    c.floats = o;
-    return c;
-}
-
-__device__ __forceinline__ void cbar(unsigned* cnt, unsigned& gen, int nw) {
-    gen += nw;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// flat copy of one gathered exchange region into LDS (poll role): n16 16-byte pairs
-template <int CH>
-__device__ __forceinline__ void poll_copy(const u64* src, int n16, float* dst, int gt, int np, u64 want, unsigned* status) {
-    for (int i0 = gt; i0 < n16; i0 += CH * np) {
-        u64 lo[CH], hi[CH];
-        int cnt = 0;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) if (i0 + k * np < n16) cnt = k + 1;
-        gather16<CH>(src + 2 * i0, 2 * np, cnt, PAIR_MASK, want, lo, hi, status);
-#pragma unroll
-        for (int k = 0; k < CH; ++k)
-            if (k < cnt) *reinterpret_cast<float4*>(dst + 4 * (long)(i0 + k * np)) = make_float4(lo_f(lo[k]), hi_f(lo[k]), lo_f(hi[k]), hi_f(hi[k]));
-    }
-}
-
-// rows of [W_ih(ctx) | W_hh]^T (registers) . dgates (bf16, LDS): output oo = BASE + STRIDE*o, o < NR -> s_out[oo]
-#define DPB_P1(NR, BASE, STRIDE)                                                                                       \
-    {                                                                                                                  \
-        float acc_[NR];                                                                                                \
-        _Pragma("unroll") for (int o = 0; o < NR; ++o) acc_[o] = 0.f;                                                  \
-        _Pragma("unroll") for (int k = 0; k < KCHB; ++k) {                                                             \
-            const uint2 g_ = *reinterpret_cast<const uint2*>(s_dg16 + 4 * (lane + 64 * k));                            \
-            _Pragma("unroll") for (int o = 0; o < NR; ++o) {                                                           \
-                acc_[o] = dot2bf(wreg[o][k].x, g_.x, acc_[o]);                                                         \
-                acc_[o] = dot2bf(wreg[o][k].y, g_.y, acc_[o]);                                                         \
-            }                                                                                                          \
-        }                                                                                                              \
-        _Pragma("unroll") for (int o = 0; o < NR; ++o) {                                                               \
-            const float sv_ = wave_sum_dpp(acc_[o]);                                                                   \
-            if (lane == 0 && (BASE) + (STRIDE) * o < nout) s_out[(BASE) + (STRIDE) * o] = sv_;                         \
-        }                                                                                                              \
-    }
-// loads the rows of this wave (same mapping) into wreg[NR][KCHB]
-#define DPB_WLOAD(NR, BASE, STRIDE)                                                                                    \
-    _Pragma("unroll") for (int o = 0; o < NR; ++o) {                                                                   \
-        const int oo = (BASE) + (STRIDE) * o;                                                                          \
-        int x = (oo < p.CPW) ? Dd + min(c_base + oo, E - 1) : XW + min(u_base + (oo - p.CPW), Dd - 1);                  \
-        if (oo >= nout) x = Dd;                                                                                        \
-        _Pragma("unroll") for (int k = 0; k < KCHB; ++k) {                                                             \
-            const int col = 4 * (lane + 64 * k);                                                                       \
-            const uint2 v = *reinterpret_cast<const uint2*>(p.wcatT16 + (long)x * R4 + min(col, R4 - 4));              \
-            wreg[o][k] = (col < R4) ? v : make_uint2(0u, 0u);                                                          \
-        }                                                                                                              \
-    }
-
-// ---- energy-backward sweep on the matrix cores ---------------------------------------------------------------------
-// The tile's (frame f, attention column a) plane is cut into 16 x 16 MFMA tiles; a wave owns up to SW_NU column units (unit
-// u -> wave u % nw, all SW_MT frame tiles of it) for the whole launch, and a lane holds the MFMA result layout of each tile:
-// column a = 16 u + (lane & 15), frames f = 16 mt + 4 (lane >> 4) + r, r < 4.  Per tile
-//   lp   = conv(f, :) . W_proj(a, :)          one v_mfma_f32_16x16x32_bf16: the K slots carry {hi.hi, lo.hi, hi.lo} of the
-//                                              split-bf16 operands, i.e. fp32-grade products from one instruction
-//   loc = tanh(lp), u = tanh(key + q + loc), du = de w_g (1 - u^2), dl = du (1 - loc^2)          (4 elements per lane)
-//   d W_proj(a, :) += dl(:, a)^T . conv       one v_mfma_f32_16x16x16_bf16: the four dl values of a lane ARE its A fragment
-// and everything that was a per-step read-modify-write before stays in registers for all L steps: dkey (4 floats per tile -
-// no atomics, one plain store at the end), d w_g, d W_proj (MFMA accumulators).  dl goes to s_dl (bf16) for the dconv
-// product; the query gradient is summed over the lane's frames here and over the four lane groups by the caller.
-typedef __attribute__((ext_vector_type(4))) short s16x4_;
-template <int NU> struct Sweep {
-    bf16x8 wpx[NU];                 // B fragment of the lp product: W_proj(a, :) in the {hi, hi, lo} slots
-    f32x4 dwp[NU];                  // d W_proj accumulator: rows a = 16 u + 4 (lane >> 4) + r, column k = lane & 15
-    float dk[NU][SW_MT][4];         // dkey of the lane's elements
-    float dwg[NU], wg[NU];
-};
-
-template <int KNMAX, int NU>
-__device__ __forceinline__ void sweep_init(Sweep<NU>& S, const float* __restrict__ Wproj, const float* __restrict__ wg, int A, int Kn, int wave, int nw, int lane) {
-    const int q = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int nu = 0; nu < NU; ++nu) {
-        const int a = 16 * (wave + nw * nu) + c;
-        const bool ok = a < A;
-        const float* wr = Wproj + (long)min(a, A - 1) * Kn;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int slot = 8 * q + i;
-            const int k = slot < KNMAX ? slot : (slot < 2 * KNMAX ? slot - KNMAX : slot - 2 * KNMAX);
-            const float w = (ok && slot < 3 * KNMAX && k < Kn) ? wr[min(k, Kn - 1)] : 0.f;
-            const __bf16 hi = (__bf16)w;
-            S.wpx[nu][i] = (slot < 2 * KNMAX) ? hi : (__bf16)(w - (float)hi);
-        }
-        S.dwp[nu] = f32x4{0.f, 0.f, 0.f, 0.f};
-        S.dwg[nu] = 0.f;
-        S.wg[nu] = ok ? wg[min(a, A - 1)] : 0.f;                    // 0: the pad columns contribute nothing
-#pragma unroll
-        for (int mt = 0; mt < SW_MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S.dk[nu][mt][r] = 0.f;
-    }
-}
-
-// one step; dq[nu] = sum of du over the lane's frames.  nu_cnt (units of this wave) and MT are wave-uniform.
-template <int NU>
-__device__ __forceinline__ void sweep_step(Sweep<NU>& S, const float (&qa)[NU], float (&dq)[NU], int nu_cnt, int wave, int nw, int MT, int TE, int A, int AP,
-                                           const unsigned short* s_cvx, const unsigned short* s_cvT, const float* s_de, const unsigned short* s_key,
-                                           unsigned short* s_dl, int lane) {
-    // The LDS addresses below (36 s_dl writes, 9 key reads, ...) are loop invariants of the time loop: left alone, the compiler
-    // hoists them into as many live registers and spills the accumulators instead.  An opaque zero ties them to the step.
-    int opaque = 0;
-    asm volatile("" : "+v"(opaque));
-    const int q = (lane >> 4) + opaque, c = lane & 15;
-#pragma unroll
-    for (int nu = 0; nu < NU; ++nu) dq[nu] = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < SW_MT; ++mt) {
-        if (mt < MT) {
-            const int f0 = 16 * mt + 4 * q;
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(s_cvx + (16 * mt + c) * CVX_LD + 8 * q);
-            const s16x4_ bv = *reinterpret_cast<const s16x4_*>(s_cvT + c * CVT_LD + f0);
-            const float4 de4 = *reinterpret_cast<const float4*>(s_de + f0);
-            const float de[4] = {de4.x, de4.y, de4.z, de4.w};
-            const int fg = min(f0, TE - 4) >> 2;                        // frames >= TE: de = 0, any finite key will do
-#pragma unroll
-            for (int nu = 0; nu < NU; ++nu) {
-                if (nu < nu_cnt) {
-                    const int a = 16 * (wave + nw * nu) + c;
-                    const f32x4 lp = mma16(av, S.wpx[nu], f32x4{0.f, 0.f, 0.f, 0.f});
-                    const uint2 kb = *reinterpret_cast<const uint2*>(s_key + ((long)fg * A + min(a, A - 1)) * 4);
-                    const float key[4] = {__uint_as_float(kb.x << 16), __uint_as_float(kb.x & 0xffff0000u),
-                                          __uint_as_float(kb.y << 16), __uint_as_float(kb.y & 0xffff0000u)};
-                    bf16x4 dl;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float loc = tanh_f(lp[r]);
-                        const float u = tanh_f(key[r] + qa[nu] + loc);
-                        const float du = de[r] * S.wg[nu] * (1.f - u * u);
-                        S.dwg[nu] += de[r] * u;
-                        dq[nu] += du;
-                        S.dk[nu][mt][r] += du;
-                        dl[r] = (__bf16)(du * (1.f - loc * loc));
-                    }
-                    const s16x4_ dls = __builtin_bit_cast(s16x4_, dl);
-                    if (f0 < TE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s_dl[(f0 + r) * AP + a] = (unsigned short)dls[r];
-                    }
-                    S.dwp[nu] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dls, bv, S.dwp[nu], 0, 0, 0);
-                }
-            }
-        }
-    }
-}
-
-// sum over the four lane groups (lanes c, c+16, c+32, c+48); every lane gets the total
-__device__ __forceinline__ float sum_groups(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-
-// sweep of this wave's units, then the Q record: the tile's query-gradient partial times (1 - q^2), pairs (a, a+1) from even lanes
-#define DPB_SWEEP_AND_PUBLISH(XB, NU)                                                                                      \
-    {                                                                                                                  \
-        float dqp_[NU];                                                                                                \
-        if (tau0 < len) sweep_step(S, qa, dqp_, nu_cnt, wave, nw, MT, TE, A, AP, s_cvx, s_cvT, s_de, s_key, s_dl, lane); \
-        else { _Pragma("unroll") for (int nu = 0; nu < NU; ++nu) dqp_[nu] = 0.f; }                                     \
-        _Pragma("unroll") for (int nu = 0; nu < NU; ++nu) {                                                            \
-            if (nu < nu_cnt) {                                                                                         \
-                const int a_ = 16 * (wave + nw * nu) + csub;                                                           \
-                const float tot_ = sum_groups(dqp_[nu]);                                                               \
-                const float mine_ = (a_ < A) ? tot_ * (1.f - qa[nu] * qa[nu]) : 0.f;                                   \
-                const float nb_ = __shfl_down(mine_, 1);                                                               \
-                if (qsub == 0 && (lane & 1) == 0 && a_ < 2 * p.QG2) {                                                  \
-                    u64* dst_ = (XB) + offQ + (long)j * p.QG2 + (a_ >> 1);                           \
-                    if (local) publish<true>(dst_, pack2(mine_, nb_, want)); else publish<false>(dst_, pack2(mine_, nb_, want)); \
-                }                                                                                                      \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-// end of the launch: d w_g and d W_proj of the wave's units -> the workgroup's slot, dkey -> HBM (plain stores, once)
-#define DPB_SWEEP_RESULTS(NU)                                                                                          \
-    {                                                                                                                  \
-        float* sl_ = p.slots + ((long)b * NT + j) * p.slot;                                                            \
-        _Pragma("unroll") for (int nu = 0; nu < NU; ++nu) {                                                            \
-            if (nu < nu_cnt) {                                                                                         \
-                const int u0_ = 16 * (wave + nw * nu);                                                                 \
-                const float g_ = sum_groups(S.dwg[nu]);                                                                \
-                if (qsub == 0 && u0_ + csub < A) sl_[u0_ + csub] = g_;                                                 \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
-                    const int a_ = u0_ + 4 * qsub + r;                                                                 \
-                    if (csub < Kn && a_ < A) sl_[A + csub * A + a_] = S.dwp[nu][r];                                    \
-                }                                                                                                      \
-                _Pragma("unroll") for (int mt = 0; mt < SW_MT; ++mt)                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                    \
-                        const int f_ = 16 * mt + 4 * qsub + r;                                                         \
-                        if (f_ < TE && tau0 + f_ < Tp && u0_ + csub < A)                                               \
-                            p.dkey[((long)b * Tp + tau0 + f_) * A + u0_ + csub] = S.dk[nu][mt][r];                     \
-                    }                                                                                                  \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-
-// conv value of (frame f, kernel k) into the two LDS images of the step's conv tile
-template <int KNMAX>
-__device__ __forceinline__ void put_cv(unsigned short* s_cvx, unsigned short* s_cvT, int f, int k, float v) {
-    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-    const unsigned short h = __builtin_bit_cast(unsigned short, hi), l = __builtin_bit_cast(unsigned short, lo);
-    unsigned short* r = s_cvx + f * CVX_LD;
-    r[k] = h; r[KNMAX + k] = l; r[2 * KNMAX + k] = h;
-    s_cvT[k * CVT_LD + f] = h;
-}
-
+// (constants, PB, the LDS carve, P1 macros, the sweep: decoder_bwd_common.h)
 // TEC: frames per tile as a compile-time constant (the bench shape), 0: taken from the plan (any multiple of 4 up to 40)
 template <int KNMAX, int TEC>
 __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
@@ -1083,6 +668,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
     const int cb = slot_id / p.NT, j = slot_id - cb * p.NT;
     const int b = cb * 8 + xcd;
     if (b >= d.B) return;
+    const unsigned epoch_ = __builtin_amdgcn_readfirstlane(p.status[EPOCH_WORD]);     // launch epoch of this work area (decoder_cluster.h)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NT = p.NT, A = d.A, E = d.E, Dd = d.Dd, Tp = d.Tp, Kn = d.Kn, Ks = d.Ks, L = d.L;
     const int ncw = (A + 63) >> 6, nct = 64 * ncw, nw = ncw + NPB;       // compute waves / threads, all waves
@@ -1171,7 +757,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         sweep_init<KNMAX>(S, p.w.Wproj, p.w.wg, A, Kn, wave, nw, lane);
         for (int t = L - 1; t >= 0; --t) {
             const int s = L - 1 - t;                                     // step counter of this launch (tags, parity)
-            const u64 want = pair_want(seq_of(s), p.epoch);
+            const u64 want = pair_want(seq_of(s), epoch_);
             const u64* base = xb(s & 1);
             DP_JIT(6)
             __syncthreads();                                            // Ba: s_dg16 holds the gate gradients of step t
@@ -1265,7 +851,7 @@ __global__ __launch_bounds__(512) void dec_bwd_persist(PB p) {
         const int lane = lz_;
         const int s = L - 1 - t;
         const long row = (long)b * L + t;
-        const u64 want = pair_want(seq_of(s), p.epoch);
+        const u64 want = pair_want(seq_of(s), epoch_);
         u64* out = xb(s & 1);
         DP_MARK(0)
         // ---- S1: cell backward of ALL hidden units (thread per unit; every workgroup of the cluster computes the same)
@@ -1550,22 +1136,44 @@ PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
     return pl;
 }
 
-__global__ void cast_rows_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int rows, int cols, int ldd) {
-    const long total = (long)rows * ldd;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / ldd), c = (int)(i - (long)r * ldd);
-        dst[i] = (c < cols) ? f2bf_bits(src[(long)r * cols + c]) : (unsigned short)0;
-    }
-}
 
 }  // namespace
 
+// decoder_stream.hip
+size_t dec_bwd_stream_work_bytes(const asr_dec_dims_t& d);
+int dec_bwd_stream_tiles(const asr_dec_dims_t& d);
+float* dec_bwd_stream_dgates(const asr_dec_dims_t& d, void* work);
+int dec_bwd_streamed(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const asr_dec_state_t& s, const int64_t* enc_len,
+                     const float* dhs, float* dxin, float* dq, float* dkey, float* slots, int slot, const float* wcatT, const float* wqT,
+                     void* work, size_t work_bytes, float** dgates_out, hipStream_t st);
+
+// 0: per-step kernels, 1: tiles resident on chip (this file), 2: streamed tiles (decoder_stream.hip)
+int dec_bwd_plan_kind(const asr_dec_dims_t& d) {
+    stream_env();
+    const PersistPlanB pl = persist_plan_b(d);
+    if (pl.ok && !g_stream_bwd) return 1;
+    return dec_bwd_stream_work_bytes(d) ? 2 : (pl.ok ? 1 : 0);
+}
 float* dec_bwd_persist_dgates(const asr_dec_dims_t& d, void* work) {
+    if (dec_bwd_plan_kind(d) == 2) return dec_bwd_stream_dgates(d, work);
     const PersistPlanB pl = persist_plan_b(d);
     return (float*)((char*)work + pl.status_bytes + pl.xbuf_bytes + pl.w16_bytes);
 }
-size_t dec_bwd_persist_work_bytes(const asr_dec_dims_t& d) { const PersistPlanB pl = persist_plan_b(d); return pl.ok ? pl.total : 0; }
-int dec_bwd_persist_tiles(const asr_dec_dims_t& d) { const PersistPlanB pl = persist_plan_b(d); return pl.ok ? pl.NT : 0; }
+// the work area is sized for whichever plan may be taken for the shape (the preference can be switched between calls)
+size_t dec_bwd_persist_work_bytes(const asr_dec_dims_t& d) {
+    const PersistPlanB pl = persist_plan_b(d);
+    return std::max(pl.ok ? pl.total : (size_t)0, dec_bwd_stream_work_bytes(d));
+}
+int dec_bwd_persist_tiles(const asr_dec_dims_t& d) {
+    const int kind = dec_bwd_plan_kind(d);
+    if (kind == 2) return dec_bwd_stream_tiles(d);
+    return kind == 1 ? persist_plan_b(d).NT : 0;
+}
+// slots are sized for the larger tile count of the two plans
+int dec_bwd_persist_tiles_max(const asr_dec_dims_t& d) {
+    const PersistPlanB pl = persist_plan_b(d);
+    return std::max(pl.ok ? pl.NT : 0, dec_bwd_stream_tiles(d));
+}
 
 // Returns ASR_OK when the whole backward loop was launched, 1 when there is no persistent plan, negative on error.
 // dhs: (B,L,Dd) gradient wrt h from the output layer; wcatT: ((Dd+E+Dd) x 4Dd) fp32 transposed [W_ih | W_hh]; wqT: (Dd x A).
@@ -1574,29 +1182,31 @@ int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
                        const float* dhs, float* dxin, float* dq, float* dkey, float* slots, int slot, const float* wcatT, const float* wqT,
                        void* work, size_t work_bytes, float** dgates_out, hipStream_t st) {
     if (g_persist_bwd < 0) { const char* e = getenv("ASR_DEC_PERSIST_BWD"); g_persist_bwd = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_persist_bwd) return 1;
+    if (dec_bwd_plan_kind(d) == 2) return dec_bwd_streamed(d, w, s, enc_len, dhs, dxin, dq, dkey, slots, slot, wcatT, wqT, work, work_bytes, dgates_out, st);
     const PersistPlanB pl = persist_plan_b(d);
-    if (!g_persist_bwd || !pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv || !s.enc16) return 1;
+    if (!pl.ok || !work || work_bytes < pl.total || ((uintptr_t)work & 255) != 0 || !s.conv || !s.enc16) return 1;
     char* base = (char*)work;
     unsigned* status = (unsigned*)base;
     u64* xbuf = (u64*)(base + pl.status_bytes);
     unsigned short* w16 = (unsigned short*)(base + pl.status_bytes + pl.xbuf_bytes);
     float* dgates = (float*)(base + pl.status_bytes + pl.xbuf_bytes + pl.w16_bytes);
     *dgates_out = dgates;
-    hipMemsetAsync(work, 0, pl.status_bytes + pl.xbuf_bytes, st);
+    clear_work(work, pl.xbuf_bytes, st);
     hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3(512), dim3(256), 0, st, wcatT, w16, d.Dd + d.E + d.Dd, 4 * d.Dd, pl.R4);
     static int allow = -1, delay = -1;
     if (allow < 0) { const char* e = getenv("ASR_LSTM_XCD_LOCAL"); allow = (e && e[0] == '0') ? 0 : 1; }
     if (delay < 0) { const char* e = getenv("ASR_DEC_BWD_POLL_DELAY"); delay = e ? atoi(e) : 0; }
     PB p{d, w, s, (const unsigned short*)s.enc16, enc_len, dhs, dxin, dq, dkey, slots, dgates, w16, wqT, xbuf, status,
-         slot, pl.NT, pl.TE, pl.UPW, pl.CPW, pl.R4, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, next_epoch(work, 7u), delay};
+         slot, pl.NT, pl.TE, pl.UPW, pl.CPW, pl.R4, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, delay};
     const int cpx = cdiv(d.B, 8), ncw = cdiv(d.A, 64);
     const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
 #define DPB_LAUNCH(KN_, TE_)                                                                                                    \
     {                                                                                                                           \
-        static bool attr = false;                                                                                               \
-        if (!attr) { hipFuncSetAttribute((const void*)dec_bwd_persist<KN_, TE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr = true; } \
+        hipFuncSetAttribute((const void*)dec_bwd_persist<KN_, TE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
         if (!grid_resident(dec_bwd_persist<KN_, TE_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                               \
         hipLaunchKernelGGL((dec_bwd_persist<KN_, TE_>), grid, block, pl.lds, st, p);                                              \
+        hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                   \
     }
     if (d.Kn <= 4) { if (pl.TE == 40) DPB_LAUNCH(4, 40) else DPB_LAUNCH(4, 0) }
     else { if (pl.TE == 40) DPB_LAUNCH(10, 40) else DPB_LAUNCH(10, 0) }

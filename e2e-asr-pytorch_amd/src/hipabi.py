@@ -130,6 +130,8 @@ _RESTYPES = {
     'asr_att_decoder_set_persistent': (ctypes.c_int, [_i]),
     'asr_att_decoder_bwd_status_offset': (_sz, [_P(DecDims)]),
     'asr_att_decoder_bwd_persistent_tiles': (ctypes.c_int, [_P(DecDims)]),
+    'asr_att_decoder_fwd_plan': (ctypes.c_int, [_P(DecDims)]),
+    'asr_att_decoder_bwd_plan': (ctypes.c_int, [_P(DecDims)]),
 }
 
 
@@ -295,7 +297,7 @@ def raise_if_aborted():
 # (engine callback), so every reader of .grad on the current stream sees complete gradients.
 # Measured on MI355X (bench.py, 1 GPU): the contractions do run beside the recurrence, but they slow it by 0.7 ms, run
 # 25-40 % slower themselves and the step gains nothing (34.2 vs 34.0 ms) - so this is OFF unless ASR_SIDE_STREAM=1.
-_side = {'stream': None, 'pending': False, 'enabled': os.environ.get('ASR_SIDE_STREAM', '0') == '1', 'deferred': []}
+_side = {'stream': None, 'pending': False, 'enabled': os.environ.get('ASR_SIDE_STREAM', '0') == '1', 'deferred': [], 'keep': []}
 
 # Round 2: with bf16 operands AND CU-masked streams the overlap pays.  The recurrence of the bf16 encoder path is launched on
 # a stream restricted to REC_UNITS compute units per XCD, the deferred parameter-gradient work on a stream restricted to the
@@ -390,6 +392,7 @@ def release_streams():
         _masked.clear()
         return
     _side['stream'], _side['deferred'], _side['pending'] = None, [], False
+    del _side['keep'][:]
     _masked.clear()
     for dev, h in handles:
         with torch.cuda.device(dev):
@@ -430,7 +433,10 @@ def side_enabled():
 class on_side_stream:
     """with on_side_stream(event, t1, t2, ...): kernels launched inside run on the side stream once `event` (recorded on the
     producing stream; None = everything issued so far on the current stream) has completed; the listed tensors are kept
-    alive for the side stream (caching-allocator record_stream)."""
+    alive (references in _side['keep']) until the current stream has joined the side stream (join_side / join_branch).
+    NOT caching-allocator record_stream: a block with a recorded stream makes the allocator record an event on that stream
+    when the tensor is freed - for tensors that die at interpreter shutdown that is a HIP call on a CU-masked stream after
+    release_streams() has destroyed it (SIGSEGV at exit, round 3's first profile run)."""
 
     def __init__(self, event, *tensors):
         self.event = event
@@ -444,8 +450,7 @@ class on_side_stream:
             side.wait_event(self.event)
         else:
             side.wait_stream(torch.cuda.current_stream())
-        for t in self.tensors:
-            t.record_stream(side)
+        _side['keep'].extend(self.tensors)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return side
@@ -469,8 +474,7 @@ class side_branch:
         side = _side['stream']
         if self.wait:
             side.wait_stream(torch.cuda.current_stream())
-        for t in self.tensors:
-            t.record_stream(side)
+        _side['keep'].extend(self.tensors)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return side
@@ -485,9 +489,7 @@ def join_branch(*tensors):
     cur = torch.cuda.current_stream()
     if _side['stream'] is not None:
         cur.wait_stream(_side['stream'])
-    for t in tensors:
-        if t is not None:
-            t.record_stream(cur)
+    _side['keep'].extend(t for t in tensors if t is not None)      # made on the side stream: freed only behind the next join_side
 
 
 def defer_side(fn, *tensors):
@@ -530,6 +532,7 @@ def join_side():
         torch.cuda.current_stream().wait_stream(_side['stream'])
     _side['pending'] = False
     _side['callback'] = False
+    del _side['keep'][:]                 # the current stream is ordered behind every side-stream user of these tensors now
 
 
 def ptr(t):

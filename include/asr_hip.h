@@ -253,8 +253,15 @@ int asr_att_decoder_fwd(const asr_dec_dims_t* dims, const asr_dec_weights_t* wei
                         const asr_dec_state_t* state, int prec, asr_stream_t stream);
 size_t asr_att_decoder_bwd_workspace_bytes(const asr_dec_dims_t* dims);
 /* bit 0 / bit 1: run the teacher-forced forward / backward loop as one persistent launch where the shape has a plan
- * (default on, env ASR_DEC_PERSIST / ASR_DEC_PERSIST_BWD); returns the previous flags.  For A/B tests. */
+ * (default on, env ASR_DEC_PERSIST / ASR_DEC_PERSIST_BWD); bit 2 / bit 3: prefer the streamed-tile plan (csrc/decoder_stream.hip)
+ * forward / backward even where the LDS-resident plan exists (env ASR_DEC_STREAM=1); returns the previous flags.  For A/B tests. */
 int asr_att_decoder_set_persistent(int flags);
+/* Which plan asr_att_decoder_fwd / _bwd take for this shape (reference loop: src/asr.py:123-175): 0 = per-step kernels,
+ * 1 = one persistent launch with the key / enc tiles resident in LDS (B <= 16 x T' <= 640, B <= 8 up to T' = 750 / 850),
+ * 2 = one persistent launch with the tiles streamed from L2 / HBM (any T', B <= 64: the reference's B = 8 batches of up to
+ * 3 400 frames, src/collect_batch.py:21-24, and BASELINE config 5). */
+int asr_att_decoder_fwd_plan(const asr_dec_dims_t* dims);
+int asr_att_decoder_bwd_plan(const asr_dec_dims_t* dims);
 /* tiles per utterance when asr_att_decoder_bwd runs the whole loop as ONE persistent launch (0: no plan for this shape,
  * the per-step kernels run); offset of that launch's 4 KB status block (abort word first) inside the workspace. */
 int asr_att_decoder_bwd_persistent_tiles(const asr_dec_dims_t* dims);

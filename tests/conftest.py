@@ -46,7 +46,7 @@ def _no_silent_abort(request):
         return
     H = sys.modules['src.hipabi']
     culprits = []
-    for t, addr in H._watch.get(torch.cuda.current_device(), []):
+    for t, addr, *_rel in H._watch.get(torch.cuda.current_device(), []):
         off = addr - t.data_ptr()
         w = t.view(torch.uint8)[off:off + 4].view(torch.int32)
         if int(w.item()):

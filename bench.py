@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--vgg', type=int, default=None, help='override model.encoder.vgg (1: VGGExtractor, 5: VGGExtractor_LN) for the SURVEY D3 variants')
     ap.add_argument('--waveform', action='store_true', help='resident input = 16 kHz waveforms; the GPU fbank (asr_fbank) runs inside the step')
     ap.add_argument('--host-input', action='store_true', help='the batch (fbank, lengths, tokens) is handed over in pinned host memory and copied to the GPU inside every step: the PCIe-inclusive rate of DESIGN.md section 6 (never the headline value)')
+    ap.add_argument('--shape', default='fixed', choices=['fixed', 'librispeech'], help="librispeech: 8 buckets per GPU with SURVEY 8d's length model clip(N(1270,480),150,2450) and the reference's halving rule (B = 8 once the longest utterance exceeds 800 frames), cycled through; --frames / --tokens are ignored")
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend for --gpus N > 1 (nccl = RCCL over xGMI; gloo only with --dry-run)')
     ap.add_argument('--dry-run', action='store_true', help='start the ranks, form the process group, exchange one all-gather and print the JSON line without touching a GPU (CPU test of the launch path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -108,6 +109,11 @@ def cpu_baseline(cfg_model, D, V, seconds, B=16, T=1200, L=180):
 
 
 def workload_string(config, args, Dfeat):
+    if args.shape == 'librispeech':
+        return ('config/librispeech_asr.yaml (vgg %d, 4xBiLSTM-320, joint CTC-att 0.5), LibriSpeech-shaped buckets per GPU: %d utterances drawn as '
+                'T ~ clip(N(1270,480),150,2450) frames x D=%d, L = 0.14 T tokens, halving rule (B = 8 when the longest > 800 frames), 8 buckets cycled, '
+                '%sdelta+SpecAugment on GPU, fwd+losses+bwd+grad-allreduce+clip+Adadelta, dropout on'
+                % (config['model']['encoder']['vgg'], args.batch, Dfeat, 'waveform in: GPU fbank + ' if args.waveform else ''))
     return ('config/librispeech_asr.yaml (vgg %d, 4xBiLSTM-320, joint CTC-att 0.5), B=%d x T=%d x D=%d per GPU, L=%d, '
             '%sdelta+SpecAugment on GPU, fwd+losses+bwd+grad-allreduce+clip+Adadelta, dropout on'
             % (config['model']['encoder']['vgg'], args.batch, args.frames, Dfeat, args.tokens, 'waveform in: GPU fbank + ' if args.waveform else ''))
@@ -195,8 +201,16 @@ def main():
     att_crit = LabelSmoothingLoss(31, 0.1) if hp.get('label_smoothing', False) else CrossEntropyLoss(ignore_index=0)
     B, T, L = args.batch, args.frames, args.tokens
     nmel = config['data']['audio']['feat_dim']
-    fbank, feat_len, txt = librispeech_shaped_batch(B, T, nmel, L, V, seed=1234 + rank, device='cuda')
-    txt_len = (txt != 0).sum(-1)
+    if args.shape == 'librispeech':
+        from src.synthetic import librispeech_length_batches
+        assert not args.waveform and not args.host_input, '--shape librispeech takes resident fbank batches'
+        batches = [(f, fl, tx, (tx != 0).sum(-1), tx.shape[1])
+                   for f, fl, tx in librispeech_length_batches(8, nmel, V, seed=1234 + rank, batch_size=B, device='cuda')]
+    else:
+        f_, fl_, tx_ = librispeech_shaped_batch(B, T, nmel, L, V, seed=1234 + rank, device='cuda')
+        batches = [(f_, fl_, tx_, (tx_ != 0).sum(-1), L)]
+    fbank, feat_len, txt, txt_len, _ = batches[0]
+    step_no = [0]
     # the 80-dim fbank batch is the resident input; delta stacking + SpecAugment (data.audio.augment) run on the GPU
     from src.audio import Delta, Augment, ExtractAudioFeature
     wav = wav_len = fb_mod = None
@@ -240,6 +254,8 @@ def main():
 
     def step_():
         nonlocal fbank, feat_len, txt, txt_len
+        fbank, feat_len, txt, txt_len, L = batches[step_no[0] % len(batches)]
+        step_no[0] += 1
         if host_batch is not None:
             fbank, feat_len, txt, txt_len = (t.to('cuda', non_blocking=True) for t in host_batch)
         feat = fbank
@@ -255,7 +271,7 @@ def main():
                           txt_len=txt_len)
 
     log('model built (%d params), warm-up...' % sum(p.numel() for p in model.parameters()))
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, len(batches) if len(batches) > 1 else 0)):      # every bucket shape once: plans, work areas
         out = step()
         torch.cuda.synchronize()
         log('warm-up step %d done, loss %.4f' % (i, float(out['total_loss'])))
@@ -264,6 +280,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    step_no[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -293,8 +310,10 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = False
     post_summ = timer.summary()
-    frames = B * T * world * args.steps
-    valid = int(feat_len.sum()) * world * args.steps
+    # padded and valid input frames of the timed steps on THIS rank (buckets cycled in order), times the ranks
+    seen = [batches[i % len(batches)] for i in range(args.steps)]
+    frames = sum(int(bt[0].shape[0] * bt[0].shape[1]) for bt in seen) * world
+    valid = sum(int(bt[1].sum()) for bt in seen) * world
     if rank != 0:
         return
 
@@ -322,7 +341,7 @@ def main():
         else:
             tidx = 5 if bwd_dom else 6
             per_bt = 4 * ((ND * Hd + 2 * ND * 4 * Hd + 2 * ND * Hd) if bwd_dom else (2 * ND * 4 * Hd + 2 * ND * Hd))
-        nbytes = sum(1.0 * (B * a[tidx] * per_bt + 4 * ND * 4 * Hd * Hd) for a, _ in calls)
+        nbytes = sum(1.0 * (a[tidx - 1] * a[tidx] * per_bt + 4 * ND * 4 * Hd * Hd) for a, _ in calls)     # a[tidx - 1] = B, a[tidx] = T of the launch
         secs = sum(ms for _, ms in calls) * 1e-3
         steps_total = sum(a[tidx] for a, _ in calls)
         # PMC traffic is quoted only when the committed collection was made on THIS workload (tools/collect_profiles.sh stores
@@ -363,16 +382,17 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         log('cpu baseline (oracle) for ~%.0f s...' % args.cpu_seconds)
-        cpu = cpu_baseline(config['model'], Dfeat, V, args.cpu_seconds, min(B, 16), T, L)
+        cpu = cpu_baseline(config['model'], Dfeat, V, args.cpu_seconds, min(B, 16), args.frames, args.tokens)
     line = {
         'metric': 'audio frames/sec (fwd+bwd) LibriSpeech-100 joint CTC-att',
         'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.prec, 'data': 'synthetic',
         'config': {'workload': workload_string(config, args, Dfeat),
-                   'global_batch': B * world, 'frames_per_utt': T, 'parallelism': 'dp%d' % world},
+                   'global_batch': (B if args.shape == 'fixed' else [int(bt[0].shape[0]) for bt in batches]) if world == 1 else B * world,
+                   'frames_per_utt': T if args.shape == 'fixed' else [int(bt[0].shape[1]) for bt in batches], 'parallelism': 'dp%d' % world},
         'valid_frames_per_s': valid / dt, 'loss': loss, 'per_rank_ms_per_step': per_rank_ms,
-        'per_rank_frames': [B * T] * world, 'host_enqueue_ms_per_step': t_host / args.steps * 1e3,
+        'per_rank_frames': [frames // world] * world, 'per_rank_max_T': [max(int(bt[0].shape[1]) for bt in batches)] * world, 'host_enqueue_ms_per_step': t_host / args.steps * 1e3,
         'stage_ms_per_step': dict([(k, v / args.steps) for k, v in tot.items()] +
                                   [(k, sum(ms for _, ms in v) / post_steps) for k, v in post_summ.items() if k not in ('asr_gemm', 'asr_gemm16')]),
         'roofline': roof, 'roofline_gemm': gemm, 'cpu_baseline': cpu,

@@ -248,6 +248,46 @@ def gen_decode():
                        'beam': 4, 'min_len_ratio': 0.01, 'max_len_ratio': 0.12}, arrays)
 
 
+
+def gen_decode_config4():
+    """G7b: BASELINE config 4 at ITS size (VERDICT r02 next #4b): config/librispeech_asr.yaml model (12 M parameters), beam 8,
+    ctc_weight 0.3, the 4 x 1024 tied RNN-LM of config/librispeech_lm.yaml with weight 0.3, T = 400 frames, max_len_ratio 0.05
+    (about a second on the CPU).  Stores seeds, the input and the reference's hypotheses + scores, not weights."""
+    from src.asr import ASR
+    from src.decode import BeamDecoder
+    from src.lm import RNNLM
+    V, D, T = 31, 160, 400
+    mc = yaml.safe_load(open(os.path.join(REF, 'config', 'librispeech_asr.yaml')))['model']
+    lm_cfg = yaml.safe_load(open(os.path.join(REF, 'config', 'librispeech_lm.yaml')))['model']
+    cfg = O.ModelCfg(mc, D, V)
+    model = ASR(D, V, 8, **mc)
+    model.load_state_dict(O.seeded_state_dict(O.param_shapes(cfg), 51))
+    model.eval()
+    lm = RNNLM(V, **lm_cfg)
+    lm_shapes = {k: tuple(v.shape) for k, v in lm.state_dict().items()}
+    lm.load_state_dict(O.seeded_state_dict(lm_shapes, 53))
+    lm.eval()
+    g = np.random.Generator(np.random.PCG64(150))
+    arrays = {}
+    nutt = 3
+    for u in range(nutt):
+        Tu = T - 37 * u
+        feat = g.random((1, Tu, D), dtype=np.float32)
+        flen = np.array([Tu], dtype=np.int64)
+        dec = BeamDecoder(model, None, beam_size=8, min_len_ratio=0.01, max_len_ratio=0.05, ctc_weight=0.3)
+        dec.apply_lm, dec.lm_w, dec.lm = True, 0.3, lm
+        with torch.no_grad():
+            hyps = dec(torch.from_numpy(feat), torch.from_numpy(flen))
+        arrays['feat%d' % u], arrays['feat_len%d' % u] = feat, flen
+        arrays['n%d' % u] = np.array(len(hyps))
+        for i, h in enumerate(hyps):
+            arrays['u%d_seq%d' % (u, i)] = np.array(h.outIndex, dtype=np.int64)
+            arrays['u%d_score%d' % (u, i)] = np.array([float(s) for s in h.output_scores], dtype=np.float32)
+            arrays['u%d_avg%d' % (u, i)] = np.array(float(h.avgScore()), dtype=np.float32)
+        print('utt', u, [(h.outIndex, round(float(h.avgScore()), 4)) for h in hyps])
+    save('g7b_decode_config4', {'model': mc, 'D': D, 'V': V, 'wseed': 51, 'lm': lm_cfg, 'lm_wseed': 53, 'beam': 8, 'min_len_ratio': 0.01,
+                                'max_len_ratio': 0.05, 'ctc_weight': 0.3, 'lm_weight': 0.3, 'nutt': nutt}, arrays)
+
 def gen_frontend():
     """G5/G6: Delta / Postprocess / Augment / mel filterbank from src/audio.py (pure torch/numpy parts).
     torchaudio, audiomentations and librosa are not installed here; the classes below never touch them,
@@ -353,7 +393,7 @@ def gen_ckpt():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['models', 'ctc', 'decode', 'frontend', 'ckpt']
+    which = sys.argv[1:] or ['models', 'ctc', 'decode', 'decode4', 'frontend', 'ckpt']
     if 'ckpt' in which:
         gen_ckpt()
     if 'models' in which:
@@ -362,5 +402,7 @@ if __name__ == '__main__':
         gen_ctc()
     if 'decode' in which:
         gen_decode()
+    if 'decode4' in which:
+        gen_decode_config4()
     if 'frontend' in which:
         gen_frontend()

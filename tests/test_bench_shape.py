@@ -27,10 +27,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, 'e2e-asr-pytorch_amd', 'config', 'librispeech_asr.yaml')
 
 
-def _setup(B, T, L, seed, train):
+def _setup(B, T, L, seed, train, vgg=0):
     from src.asr import ASR
     from src.synthetic import librispeech_shaped_batch
     mc = yaml.safe_load(open(CFG))['model']
+    mc['encoder']['vgg'] = vgg
     D, V = 160, 31
     cfg = O.ModelCfg(mc, D, V)
     sd = O.seeded_state_dict(O.param_shapes(cfg), 11)
@@ -61,7 +62,8 @@ def _hip_step(model, feat, lens, txt):
 
 
 def _dropout_masks(model, cfg, B, T):
-    """The masks the HIP step used: layer l's LSTM output has T_l frames (T, T, T/2, T/2 for rates 1,2,1,1)."""
+    """The masks the HIP step used: layer l's LSTM output has T_l frames (T, T, T/2, T/2 for rates 1,2,1,1; T = the frames
+    that reach the first recurrent layer: a quarter of the input behind a VGG front-end)."""
     from src import hipabi as H
     masks, Tl = [], T
     rates = cfg.enc_sample_rate
@@ -124,6 +126,34 @@ def test_bench_shape_train_step_vs_oracle():
     assert plans['dec_fwd_work'] > 0 and plans['dec_bwd_tiles'] > 0, plans
     res = _hip_step(model, feat, lens, txt)
     masks = _dropout_masks(model, cfg, B, T)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.asr_losses(feat, lens, txt, P, cfg, label_smoothing=False, drop_masks=masks, lstm_impl=O.bilstm_aten)
+    ref['total_loss'].backward()
+    assert np.array_equal(res['enc_len'].cpu().numpy(), ref['enc_len'].numpy())
+    report = []
+    _compare(model, res, ref, P, report)
+    _finish(report)
+
+
+@pytest.mark.parametrize('vgg', [1, 5])
+def test_bench_shape_vgg_train_step_vs_oracle(vgg):
+    """The vgg 1 (VGGExtractor) and vgg 5 (VGGExtractor_LN) bench lines (B=16 x T=1200 x L=100, T' = T/8 = 150) against the
+    oracle: the implicit-GEMM convolutions at (16, C, 1200, 40), the recurrences at T/4 and T/8 frames, and the persistent
+    decoder plans for short encoder outputs - 150 frames only get an on-chip backward plan through the frame-less tiles of
+    round 2 (tiles past T' that carry weight rows only), which no small fixture reaches.
+    Reference: src/module.py:582-716, src/asr.py:459-464."""
+    from src import functions as F_hip
+    from src import hipabi as H
+    B, T, L = 16, 1200, 100
+    mc, cfg, sd, model, feat, lens, txt = _setup(B, T, L, seed=99 + vgg, train=True, vgg=vgg)
+    d = F_hip._dec_dims(model, B, T // 8, L)
+    assert int(H.lib().asr_att_decoder_fwd_plan(ctypes.byref(d))) == 1
+    assert int(H.lib().asr_att_decoder_bwd_plan(ctypes.byref(d))) == 1, 'T\' = 150 must take the on-chip backward plan (frame-less tiles)'
+    tiles = int(H.lib().asr_att_decoder_bwd_persistent_tiles(ctypes.byref(d)))
+    assert tiles >= 15 and tiles * 8 <= 8 * 16, tiles            # 15+ workgroups per utterance for 150 frames: some carry weight rows only
+    res = _hip_step(model, feat, lens, txt)
+    masks = _dropout_masks(model, cfg, B, T // 4)
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref = O.asr_losses(feat, lens, txt, P, cfg, label_smoothing=False, drop_masks=masks, lstm_impl=O.bilstm_aten)

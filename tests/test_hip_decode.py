@@ -103,3 +103,54 @@ def test_device_beam_search_batched_equals_single_and_host_path(g7, ctc_w, lm_w,
             assert a.outIndex == b.outIndex == c.outIndex, (u, a.outIndex, b.outIndex, c.outIndex)
             np.testing.assert_allclose(np.array(a.output_scores), np.array(b.output_scores), rtol=1e-5, atol=1e-5)
             np.testing.assert_allclose(np.array(a.output_scores), np.array(c.output_scores), rtol=1e-4, atol=2e-3)
+
+
+def test_config4_size_beam_search_matches_reference(golden_dir):
+    """BASELINE config 4 at its size: the 12 M-parameter model of config/librispeech_asr.yaml, beam 8,
+    ctc_weight 0.3, the 4 x 1024 tied RNN-LM with weight 0.3, T = 400 / 363 / 326 frames, max_len_ratio 0.05 - against
+    hypotheses and scores the imported reference produced (tests/golden/gen_golden.py::gen_decode_config4), decoded one utterance
+    at a time and as one zero-padded batch.  With seeded random weights the reference's eight hypotheses are near-ties (average
+    scores within 3e-3 of each other), so the comparison is by content, not by rank: the best average score, every reference
+    hypothesis that we also return token for token with its per-token scores, at least six of the eight sequences in common,
+    and nothing of ours worse than the reference's worst by more than the tie margin.  fp32 contraction mode."""
+    from src.asr import ASR
+    from src.decode import BeamDecoder
+    from src.lm import RNNLM
+    z = np.load(os.path.join(golden_dir, 'g7b_decode_config4.npz'))
+    meta = yaml.safe_load(str(z['meta']))
+    cfg = O.ModelCfg(meta['model'], meta['D'], meta['V'])
+    model = ASR(meta['D'], meta['V'], 8, prec='fp32', **meta['model'])
+    model.load_state_dict(O.seeded_state_dict(O.param_shapes(cfg), meta['wseed']))
+    model = model.cuda().eval()
+    dec = BeamDecoder(model, None, beam_size=meta['beam'], min_len_ratio=meta['min_len_ratio'], max_len_ratio=meta['max_len_ratio'],
+                      ctc_weight=meta['ctc_weight'])
+    lm = RNNLM(meta['V'], **meta['lm'])
+    lm.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in lm.state_dict().items()}, meta['lm_wseed']))
+    dec.set_lm(lm.cuda().eval(), meta['lm_weight'])
+    nutt = meta['nutt']
+    lens = [int(z['feat_len%d' % u][0]) for u in range(nutt)]
+    feats = torch.zeros(nutt, max(lens), meta['D'])
+    for u in range(nutt):
+        feats[u, :lens[u]] = torch.from_numpy(z['feat%d' % u][0])
+    batched = dec(feats.cuda(), torch.tensor(lens).cuda())
+
+    def check(hyps, u, what):
+        ref = [(z['u%d_seq%d' % (u, i)].tolist(), z['u%d_score%d' % (u, i)], float(z['u%d_avg%d' % (u, i)])) for i in range(int(z['n%d' % u]))]
+        assert len(hyps) == len(ref), (what, u, len(hyps), len(ref))
+        assert abs(hyps[0].avgScore() - ref[0][2]) < 2e-3, (what, u, hyps[0].avgScore(), ref[0][2])
+        ours = {tuple(h.outIndex): h for h in hyps}
+        common = 0
+        for seq, scores, avg in ref:
+            h = ours.get(tuple(seq))
+            if h is not None:
+                common += 1
+                np.testing.assert_allclose(np.array(h.output_scores, dtype=np.float32), scores, rtol=1e-4, atol=2e-3)
+                assert abs(h.avgScore() - avg) < 2e-3
+        assert common >= len(ref) - 2, (what, u, common, [h.outIndex for h in hyps], [r[0] for r in ref])
+        worst = min(r[2] for r in ref)
+        assert all(h.avgScore() > worst - 3e-3 for h in hyps), (what, u)
+        assert all(len(h.outIndex) == len(ref[0][0]) for h in hyps)
+
+    for u in range(nutt):
+        check(batched[u], u, 'batched')
+        check(dec(feats[u:u + 1, :lens[u]].cuda(), torch.tensor(lens[u:u + 1]).cuda()), u, 'single')

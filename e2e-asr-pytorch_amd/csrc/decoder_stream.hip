@@ -287,47 +287,66 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                 if (tau0 + i < Tp) p.s.conv[(row * Kn + k) * Tp + tau0 + i] = v;
             }
         }
+        // key fragments of the first KPF 16-frame tiles: requested before the barrier (they do not depend on the query), so the
+        // sweep starts on data that is already there; inside the sweep a fragment is re-requested for tile mt + KPF as soon as
+        // tile mt has consumed it - KPF tiles (8 waves x 64 lanes x 24 B x KPF = 98 KB per CU) in flight against the ~2 us of an
+        // HBM / Infinity-Cache miss at config 5 (one tile ahead left the stream latency-bound: 12 KB in flight, ~6 GB/s per CU)
+        constexpr int KPF = 6;
+        uint2 kr[KPF][FSW_NU];
+        int acol[FSW_NU];
+        const int q_ = lane >> 4, c_ = lane & 15;
+#pragma unroll
+        for (int nu = 0; nu < FSW_NU; ++nu) acol[nu] = min(16 * (wave + NCW * nu) + c_, A - 1);
+        const unsigned short* kb0 = p.key16t + (((long)b * G4 + (tau0 >> 2) + q_) * A) * 4;
+        if (MTV > 0) {
+#pragma unroll
+            for (int u = 0; u < KPF; ++u)
+#pragma unroll
+                for (int nu = 0; nu < FSW_NU; ++nu)
+                    kr[u][nu] = *reinterpret_cast<const uint2*>(kb0 + ((long)4 * min(u, MTV - 1) * A + acol[nu]) * 4);
+        }
         __syncthreads();                                                // B2: s_q holds q_t, s_cvx the tile's conv
-        // ---- energies of the tile on the matrix cores, 16 frames at a time, the next tile's key fragment in flight
+        // ---- energies of the tile on the matrix cores, 16 frames at a time
         {
             int opaque = 0;
             asm volatile("" : "+v"(opaque));
-            const int q = (lane >> 4) + opaque, c = lane & 15;
+            const int q = q_ + opaque, c = c_;
             float qv[FSW_NU];
-            int acol[FSW_NU];
 #pragma unroll
-            for (int nu = 0; nu < FSW_NU; ++nu) { acol[nu] = min(16 * (wave + NCW * nu) + c, A - 1); qv[nu] = s_q[acol[nu]]; }
-            const unsigned short* kb0 = p.key16t + (((long)b * G4 + (tau0 >> 2) + q) * A) * 4;
-            uint2 kcur[FSW_NU], knext[FSW_NU];
+            for (int nu = 0; nu < FSW_NU; ++nu) qv[nu] = s_q[acol[nu]];
+            for (int mt0 = 0; mt0 < MTV; mt0 += KPF) {
 #pragma unroll
-            for (int nu = 0; nu < FSW_NU; ++nu) kcur[nu] = *reinterpret_cast<const uint2*>(kb0 + (long)acol[nu] * 4);
-            for (int mt = 0; mt < MTV; ++mt) {
-                const int mtn = min(mt + 1, MTV - 1);
+                for (int u = 0; u < KPF; ++u) {
+                    const int mt = mt0 + u;
+                    if (mt < MTV) {
+                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(s_cvx + (16 * mt + c) * FCVX_LD + 8 * q);
+                        float ep[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int nu = 0; nu < FSW_NU; ++nu) knext[nu] = *reinterpret_cast<const uint2*>(kb0 + ((long)4 * mtn * A + acol[nu]) * 4);
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(s_cvx + (16 * mt + c) * FCVX_LD + 8 * q);
-                float ep[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int nu = 0; nu < FSW_NU; ++nu) {
+                            if (nu < nu_cnt) {
+                                const f32x4 lp = mma16(av, wpx[nu], f32x4{0.f, 0.f, 0.f, 0.f});
+                                const uint2 kb = kr[u][nu];
+                                const float key[4] = {__uint_as_float(kb.x << 16), __uint_as_float(kb.x & 0xffff0000u),
+                                                      __uint_as_float(kb.y << 16), __uint_as_float(kb.y & 0xffff0000u)};
 #pragma unroll
-                for (int nu = 0; nu < FSW_NU; ++nu) {
-                    if (nu < nu_cnt) {
-                        const f32x4 lp = mma16(av, wpx[nu], f32x4{0.f, 0.f, 0.f, 0.f});
-                        const uint2 kb = kcur[nu];
-                        const float key[4] = {__uint_as_float(kb.x << 16), __uint_as_float(kb.x & 0xffff0000u),
-                                              __uint_as_float(kb.y << 16), __uint_as_float(kb.y & 0xffff0000u)};
+                                for (int r = 0; r < 4; ++r) ep[r] += wgu[nu] * tanh_f(key[r] + qv[nu] + tanh_f(lp[r]));
+                            }
+                        }
+                        if (mt + KPF < MTV) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ep[r] += wgu[nu] * tanh_f(key[r] + qv[nu] + tanh_f(lp[r]));
+                            for (int nu = 0; nu < FSW_NU; ++nu)
+                                kr[u][nu] = *reinterpret_cast<const uint2*>(kb0 + ((long)4 * (mt + KPF) * A + acol[nu]) * 4);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = ep[r];
+#define DPF_STEP(CTRL) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+                            DPF_STEP(0xB1) DPF_STEP(0x4E) DPF_STEP(0x141) DPF_STEP(0x140)      // sum over the 16 lanes of the row
+#undef DPF_STEP
+                            if (c == 0) s_epart[wave * TEB + 16 * mt + 4 * q + r] = v;
+                        }
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = ep[r];
-#define DPF_STEP(CTRL) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-                    DPF_STEP(0xB1) DPF_STEP(0x4E) DPF_STEP(0x141) DPF_STEP(0x140)      // sum over the 16 lanes of the row
-#undef DPF_STEP
-                    if (c == 0) s_epart[wave * TEB + 16 * mt + 4 * q + r] = v;
-                }
-#pragma unroll
-                for (int nu = 0; nu < FSW_NU; ++nu) kcur[nu] = knext[nu];
             }
         }
         compute_barrier(&s_bar, gen);                                   // c3: s_epart complete
@@ -364,23 +383,23 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
             for (int w8 = 0; w8 < NCW; ++w8) ssum += s_red[1][w8];
         }
         // ---- partial context of the tile: sum_f w[f] enc[f, :], the enc rows streamed as 16-byte chunks; thread = (chunk,
-        //      frame group), four rows in flight, the frame groups meet in LDS
+        //      frame group), eight rows in flight (61 KB per CU), the frame groups meet in LDS
         {
             const int cg = tz % nch, fg = tz / nch;
             if (fg < NG) {
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const unsigned short* er = reinterpret_cast<const unsigned short*>(p.s.enc16) + ((long)b * Tp + tau0) * E + 8 * cg;
-                for (int f = fg; f < nf; f += 4 * NG) {
-                    uint4 x[4];
-                    float wv[4];
+                for (int f = fg; f < nf; f += 8 * NG) {
+                    uint4 x[8];
+                    float wv[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const int fu = min(f + u * NG, nf - 1);
                         x[u] = *reinterpret_cast<const uint4*>(er + (long)fu * E);
                         wv[u] = (f + u * NG < nf) ? s_w[fu] : 0.f;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         acc[0] += wv[u] * __uint_as_float(x[u].x << 16); acc[1] += wv[u] * __uint_as_float(x[u].x & 0xffff0000u);
                         acc[2] += wv[u] * __uint_as_float(x[u].y << 16); acc[3] += wv[u] * __uint_as_float(x[u].y & 0xffff0000u);
                         acc[4] += wv[u] * __uint_as_float(x[u].z << 16); acc[5] += wv[u] * __uint_as_float(x[u].z & 0xffff0000u);
@@ -672,10 +691,12 @@ __host__ __device__ inline SBCarve sbwd_carve(int TEB, int A, int E, int Kn, int
     return c;
 }
 
-// one 48-frame group of the energy-backward sweep (decoder_bwd_common.h::sweep_step with the key fragment in registers and
-// the dkey contribution returned instead of accumulated)
+// one 48-frame group of the energy-backward sweep (decoder_bwd_common.h::sweep_step with the key fragment in registers): the dkey
+// contribution of a (unit, 16-frame tile) is added to the value read ahead (`old`) and stored at once, and the tile's key
+// fragment is re-requested for the NEXT group as soon as it has been consumed - neither lives longer than it must
 template <int NU>
-__device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU], float (&dq)[NU], float (&dk)[NU][SW_MT][4], const uint2 (&kf)[NU][SW_MT],
+__device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU], float (&dq)[NU], const float4 (&old)[NU][SW_MT], uint2 (&kf)[NU][SW_MT],
+                                            float* dk_g, const unsigned short* key_next, const int (&acol)[NU], int A, int MTB_left_next,
                                             int nu_cnt, int wave, int nw, int MTg, int AP, const unsigned short* s_cvx, const unsigned short* s_cvT,
                                             const float* s_de, unsigned short* s_dl, int lane) {
     int opaque = 0;
@@ -697,7 +718,9 @@ __device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU],
                     const uint2 kb = kf[nu][mt];
                     const float key[4] = {__uint_as_float(kb.x << 16), __uint_as_float(kb.x & 0xffff0000u),
                                           __uint_as_float(kb.y << 16), __uint_as_float(kb.y & 0xffff0000u)};
+                    if (key_next) kf[nu][mt] = *reinterpret_cast<const uint2*>(key_next + ((long)4 * min(mt, MTB_left_next - 1) * A + acol[nu]) * 4);
                     bf16x4 dl;
+                    float du4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float loc = tanh_f(lp[r]);
@@ -705,8 +728,12 @@ __device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU],
                         const float du = de[r] * S.wg[nu] * (1.f - u * u);
                         S.dwg[nu] += de[r] * u;
                         dq[nu] += du;
-                        dk[nu][mt][r] = du;
+                        du4[r] = du;
                         dl[r] = (__bf16)(du * (1.f - loc * loc));
+                    }
+                    if (a < A) {
+                        const float4 o = old[nu][mt];
+                        *reinterpret_cast<float4*>(dk_g + ((long)4 * mt * A + acol[nu]) * 4) = make_float4(o.x + du4[0], o.y + du4[1], o.z + du4[2], o.w + du4[3]);
                     }
                     const s16x4_ dls = __builtin_bit_cast(s16x4_, dl);
 #pragma unroll
@@ -720,7 +747,7 @@ __device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU],
 
 // All 48-frame groups of the tile for one step (both roles: the polling waves own sweep units too).  COMPUTE waves also stage
 // the next group's conv tile and run the dconv product of the group (P4).  Returns the tile's query-gradient partial in dqt.
-template <int KNMAX, int NU, bool COMPUTE>
+template <int KNMAX, int NU, bool COMPUTE, bool DKPF>
 __device__ __forceinline__ void sweep_tile(const PSB& p, Sweep<NU>& S, const float (&qa)[NU], float (&dqt)[NU], int nu_cnt, int wave, int nw, int lane, int tz,
                                            int nct, int b, int j, int tau0, int nf, int len, long row, int AP,
                                            unsigned short* s_cvx, unsigned short* s_cvT, const float* s_de, unsigned short* s_dl,
@@ -748,55 +775,48 @@ __device__ __forceinline__ void sweep_tile(const PSB& p, Sweep<NU>& S, const flo
     const int GF = 16 * SW_MT;
     const int cvk0 = min(cvi0, Kn * GF - 1) / GF, cvf0 = min(cvi0, Kn * GF - 1) - cvk0 * GF;
     const int cvk1 = min(cvi1, Kn * GF - 1) / GF, cvf1 = min(cvi1, Kn * GF - 1) - cvk1 * GF;
+    float4 oldn[NU][SW_MT];
     for (int g = 0; g < NGRP; ++g) {
         const int MTg = min(SW_MT, MTB - SW_MT * g);
         const int fg0 = GF * g;                                          // first frame of the group inside the tile
-        // dkey of the group's elements: requested now, added and stored behind the sweep
+        // dkey of the group's elements: requested now, added and stored inside the sweep; DKPF (tiles streamed from HBM: the
+        // latency of the read would be exposed once per group): requested one group ahead
         float4 old[NU][SW_MT];
-#pragma unroll
-        for (int nu = 0; nu < NU; ++nu)
-#pragma unroll
-            for (int mt = 0; mt < SW_MT; ++mt)
-                old[nu][mt] = *reinterpret_cast<const float4*>(p.dkT + ((g0 + 4 * min(SW_MT * g + mt, MTB - 1)) * A + acol[nu]) * 4);
-        uint2 kn[NU][SW_MT];
-        float cn0 = 0.f, cn1 = 0.f;
-        if (g + 1 < NGRP) {
+        if (!DKPF || g == 0) {
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu)
 #pragma unroll
                 for (int mt = 0; mt < SW_MT; ++mt)
-                    kn[nu][mt] = *reinterpret_cast<const uint2*>(p.key16t + ((g0 + 4 * min(SW_MT * (g + 1) + mt, MTB - 1)) * A + acol[nu]) * 4);
-            if (COMPUTE) {
-                const int fa = tau0 + fg0 + GF + cvf0, fb = tau0 + fg0 + GF + cvf1;
-                cn0 = p.s.conv[(row * Kn + cvk0) * Tp + min(fa, Tp - 1)];
-                cn1 = p.s.conv[(row * Kn + cvk1) * Tp + min(fb, Tp - 1)];
-                if (fa >= Tp) cn0 = 0.f;
-                if (fb >= Tp) cn1 = 0.f;
-            }
+                    old[nu][mt] = *reinterpret_cast<const float4*>(p.dkT + ((g0 + 4 * min(SW_MT * g + mt, MTB - 1)) * A + acol[nu]) * 4);
         } else {
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu)
 #pragma unroll
-                for (int mt = 0; mt < SW_MT; ++mt) kn[nu][mt] = kf[nu][mt];
+                for (int mt = 0; mt < SW_MT; ++mt) old[nu][mt] = oldn[nu][mt];
         }
-        float dk[NU][SW_MT][4];
+        if (DKPF && g + 1 < NGRP) {
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu)
+#pragma unroll
+                for (int mt = 0; mt < SW_MT; ++mt)
+                    oldn[nu][mt] = *reinterpret_cast<const float4*>(p.dkT + ((g0 + 4 * min(SW_MT * (g + 1) + mt, MTB - 1)) * A + acol[nu]) * 4);
+        }
+        float cn0 = 0.f, cn1 = 0.f;
+        if (COMPUTE && g + 1 < NGRP) {
+            const int fa = tau0 + fg0 + GF + cvf0, fb = tau0 + fg0 + GF + cvf1;
+            cn0 = p.s.conv[(row * Kn + cvk0) * Tp + min(fa, Tp - 1)];
+            cn1 = p.s.conv[(row * Kn + cvk1) * Tp + min(fb, Tp - 1)];
+            if (fa >= Tp) cn0 = 0.f;
+            if (fb >= Tp) cn1 = 0.f;
+        }
         float dqg[NU];
 #pragma unroll
         for (int nu = 0; nu < NU; ++nu) dqg[nu] = 0.f;
-        sweep_group<NU>(S, qa, dqg, dk, kf, nu_cnt, wave, nw, MTg, AP, s_cvx, s_cvT, s_de + fg0, s_dl, lane);
+        const unsigned short* key_next = (g + 1 < NGRP) ? p.key16t + (g0 + 4 * SW_MT * (g + 1)) * A * 4 : nullptr;
+        sweep_group<NU>(S, qa, dqg, old, kf, p.dkT + (g0 + 4 * SW_MT * g) * A * 4, key_next, acol, A, MTB - SW_MT * (g + 1),
+                        nu_cnt, wave, nw, MTg, AP, s_cvx, s_cvT, s_de + fg0, s_dl, lane);
 #pragma unroll
-        for (int nu = 0; nu < NU; ++nu) {
-            dqt[nu] += dqg[nu];
-            if (nu < nu_cnt && 16 * (wave + nw * nu) + c < A) {
-#pragma unroll
-                for (int mt = 0; mt < SW_MT; ++mt)
-                    if (mt < MTg) {
-                        float4 v = old[nu][mt];
-                        v.x += dk[nu][mt][0]; v.y += dk[nu][mt][1]; v.z += dk[nu][mt][2]; v.w += dk[nu][mt][3];
-                        *reinterpret_cast<float4*>(p.dkT + ((g0 + 4 * (SW_MT * g + mt)) * A + acol[nu]) * 4) = v;
-                    }
-            }
-        }
+        for (int nu = 0; nu < NU; ++nu) dqt[nu] += dqg[nu];
         __syncthreads();                                                // G1: s_dl of the group complete
         if (COMPUTE) {
             // P4: dconv (16 x Kn) = dl (16 x A) . W_proj (A x Kn) on the matrix cores, one 16-frame tile per wave
@@ -828,10 +848,6 @@ __device__ __forceinline__ void sweep_tile(const PSB& p, Sweep<NU>& S, const flo
                 if (cvi1 < Kn * GF) put_cv<KNMAX>(s_cvx, s_cvT, cvf1, cvk1, cn1);
             }
         }
-#pragma unroll
-        for (int nu = 0; nu < NU; ++nu)
-#pragma unroll
-            for (int mt = 0; mt < SW_MT; ++mt) kf[nu][mt] = kn[nu][mt];
         __syncthreads();                                                // G2: the next group's conv tile is staged, s_dl is free
     }
     if (COMPUTE) {
@@ -874,7 +890,9 @@ __device__ __forceinline__ void sweep_tile(const PSB& p, Sweep<NU>& S, const flo
         }                                                                                                              \
     }
 
-template <int KNMAX>
+// RESIDENT: the workgroup's CPW + UPW rows of the transposed cell weights fit the registers (B <= 16: at most 59 rows); otherwise
+// every row is streamed from L2 and the 80 registers go to prefetching (dkey one group ahead)
+template <int KNMAX, bool RESIDENT>
 __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_bar;
@@ -942,7 +960,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
     for (int i = tid; i < NDE; i += blockDim.x) s_de[i] = 0.f;
     const int u_base = j * p.UPW, c_base = j * p.CPW;
     const int nout = p.CPW + p.UPW;
-    const int RES = RCB * ncw + RPB * NPB;                              // register-resident outputs of P1
+    const int RES = RESIDENT ? RCB * ncw + RPB * NPB : 0;                 // register-resident outputs of P1
     const int nunits = (A + 15) >> 4;
     const int nu_cnt = (nunits - wave + nw - 1) / nw;
     const int qsub = lane >> 4, csub = lane & 15;
@@ -955,8 +973,8 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
         // =========================== polling role ===========================
         const int gt = tid - nct, np = 64 * NPB;
         const int obase = RCB * ncw + (wave - ncw);
-        uint2 wreg[RPB][KCHB];
-        DPB_WLOAD(RPB, obase, NPB)
+        uint2 wreg[RESIDENT ? RPB : 1][KCHB];
+        if (RESIDENT) { DPB_WLOAD((RESIDENT ? RPB : 1), obase, NPB) }
         Sweep<SW_NUP> S;
         sweep_init<KNMAX>(S, p.w.Wproj, p.w.wg, A, Kn, wave, nw, lane);
         for (int t = L - 1; t >= 0; --t) {
@@ -965,7 +983,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
             const u64 want = pair_want(seq_of(s), epoch_);
             u64* base = xb(s & 1);
             __syncthreads();                                            // Ba: s_dg16 holds the gate gradients of step t
-            DPB_P1(RPB, obase, NPB)
+            if (RESIDENT) { DPB_P1((RESIDENT ? RPB : 1), obase, NPB) }
             DSB_P1_EXTRA(wave, nw)
             __syncthreads();                                            // Bb: s_out complete
             poll_copy<4>(base + offC, NT * p.CG2 / 2, s_crec, gt, np, want, p.status);
@@ -975,7 +993,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
             __syncthreads();                                            // H2
             __syncthreads();                                            // X1: s_de, the first group's conv tile complete
             float dqt[SW_NUP];
-            sweep_tile<KNMAX, SW_NUP, false>(p, S, qa, dqt, nu_cnt, wave, nw, lane, tid, nct, b, j, tau0, nf, len, row, AP,
+            sweep_tile<KNMAX, SW_NUP, false, !RESIDENT>(p, S, qa, dqt, nu_cnt, wave, nw, lane, tid, nct, b, j, tau0, nf, len, row, AP,
                                               s_cvx, s_cvT, s_de, s_dl, s_wp16, base, offV, local, want);
 #pragma unroll
             for (int nu = 0; nu < SW_NUP; ++nu) {
@@ -1047,8 +1065,8 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
 
     // =========================== compute role ===========================
     unsigned gen = 0;
-    uint2 wreg[RCB][KCHB];
-    DPB_WLOAD(RCB, wave, ncw)
+    uint2 wreg[RESIDENT ? RCB : 1][KCHB];
+    if (RESIDENT) { DPB_WLOAD((RESIDENT ? RCB : 1), wave, ncw) }
     Sweep<SW_NU> S;
     sweep_init<KNMAX>(S, p.w.Wproj, p.w.wg, A, Kn, wave, nw, lane);
     const int a = tid;
@@ -1098,7 +1116,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
         }
         __syncthreads();                                                // Ba
         // ---- P1: dctx slice and the recurrent part of dh_{t-1} for the own units
-        DPB_P1(RCB, wave, ncw)
+        if (RESIDENT) { DPB_P1((RESIDENT ? RCB : 1), wave, ncw) }
         DSB_P1_EXTRA(wave, nw)
         __syncthreads();                                                // Bb
         // ---- C record {dctx slice | dh_rec slice} + global dxin (context part)
@@ -1161,11 +1179,17 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
             for (int w = 0; w < ncw; ++w) dot += s_red[w];
             for (int fp = 0; fp < nf; fp += FPP) {
                 const int f = fp + f2;
-                uint4 xn[10];
-                {
+                // streamed-from-HBM tiles (ten passes): the next pass's rows are requested before this pass is consumed; small
+                // tiles (one or two passes, L2-resident) re-request in place and keep the 40 registers
+                uint4 xn[RESIDENT ? 1 : 10];
+                if (!RESIDENT) {
                     const unsigned short* er = erow + (long)min(f + FPP, nf - 1) * E;
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) xn[u] = *reinterpret_cast<const uint4*>(er + 8 * min(part + 8 * u, (E >> 3) - 1));
+                    for (int u = 0; u < 10; ++u) xn[RESIDENT ? 0 : u] = *reinterpret_cast<const uint4*>(er + 8 * min(part + 8 * u, (E >> 3) - 1));
+                } else if (fp > 0) {
+                    const unsigned short* er = erow + (long)min(f, nf - 1) * E;
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) x[u] = *reinterpret_cast<const uint4*>(er + 8 * min(part + 8 * u, (E >> 3) - 1));
                 }
                 const float attf = p.s.att[row * Tp + min(tau0 + min(f, nf - 1), Tp - 1)];
                 float v = 0.f;
@@ -1187,8 +1211,10 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
                     s_de[f] = dev;
                     dbg += dev;
                 }
+                if (!RESIDENT) {
 #pragma unroll
-                for (int u = 0; u < 10; ++u) x[u] = xn[u];
+                    for (int u = 0; u < 10; ++u) x[u] = xn[RESIDENT ? 0 : u];
+                }
             }
             for (int f = nf + tz; f < NDE; f += nct) s_de[f] = 0.f;     // frames past the utterance (and what P5 left there)
         }
@@ -1196,7 +1222,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
         // ---- P3 / P4: energy backward sweep and dconv of every 48-frame group, then this wave's query-gradient partials (Q record)
         {
             float dqt[SW_NU];
-            sweep_tile<KNMAX, SW_NU, true>(p, S, qa, dqt, nu_cnt, wave, nw, lane, tz, nct, b, j, tau0, nf, len, row, AP,
+            sweep_tile<KNMAX, SW_NU, true, !RESIDENT>(p, S, qa, dqt, nu_cnt, wave, nw, lane, tz, nct, b, j, tau0, nf, len, row, AP,
                                             s_cvx, s_cvT, s_de, s_dl, s_wp16, out, offV, local, want);
 #pragma unroll
             for (int nu = 0; nu < SW_NU; ++nu) {
@@ -1393,14 +1419,16 @@ int dec_bwd_streamed(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const 
           slot, pl.NT, pl.TEB, pl.UPW, pl.CPW, pl.R4, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, delay};
     const int cpx = cdiv(d.B, 8), ncw = cdiv(d.A, 64);
     const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
-#define DSB_LAUNCH(KN_)                                                                                                         \
+#define DSB_LAUNCH(KN_, RES_)                                                                                                   \
     {                                                                                                                           \
-        hipFuncSetAttribute((const void*)dec_bwd_stream<KN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);   \
-        if (!grid_resident(dec_bwd_stream<KN_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                                   \
-        hipLaunchKernelGGL((dec_bwd_stream<KN_>), grid, block, pl.lds, st, p);                                                  \
+        hipFuncSetAttribute((const void*)dec_bwd_stream<KN_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
+        if (!grid_resident(dec_bwd_stream<KN_, RES_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                             \
+        hipLaunchKernelGGL((dec_bwd_stream<KN_, RES_>), grid, block, pl.lds, st, p);                                            \
         hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                 \
     }
-    if (d.Kn <= 4) DSB_LAUNCH(4) else DSB_LAUNCH(10)
+    const bool resident = pl.CPW + pl.UPW <= RCB * ncw + RPB * NPB;
+    if (d.Kn <= 4) { if (resident) DSB_LAUNCH(4, true) else DSB_LAUNCH(4, false) }
+    else { if (resident) DSB_LAUNCH(10, true) else DSB_LAUNCH(10, false) }
 #undef DSB_LAUNCH
     hipLaunchKernelGGL(dkey_untranspose_kernel, dim3(2048), dim3(256), 0, st, dkT, dkey, d.B, d.Tp, d.A, (long)pl.NT * pl.TEB / 4);
     hipError_t e = hipGetLastError();

@@ -51,90 +51,70 @@ __device__ __forceinline__ unsigned seq_of(int s) { return (unsigned)((s >> 1) %
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-// One polling round: CH `global_load_dwordx4 ... sc1` AND their `s_waitcnt vmcnt(0)` as ONE asm statement, for every CH.
-// The destination registers are early-clobber outputs of that single statement, so for the compiler they come into
-// existence already complete: no use, copy or spill of a destination can be scheduled between a load and the wait.
-// (Round 2 had this form for CH <= 3 and 5 only; for the other widths the loads and the wait were separate statements and
-// the tag checks were once scheduled in front of the wait, where the registers still held the previous poll - the
-// intermittent decoder deviations of round 2, DESIGN.md section 2.  tests/test_handoff_isa.py disassembles the built
-// objects and checks that nothing touches a poll destination between its load and the wait.)
-// Inline asm because the loads must be re-issued every round; the gather waves have nothing else in their vector-memory
-// queue, so `s_waitcnt vmcnt(0)` is exact.  2 * CH operands <= 20 of the 30 an asm statement may carry.
-#define G16_LD(o, i) "global_load_dwordx4 %" #o ", %" #i ", off sc1\n\t"
+// Fetches the 16-byte granule PAIRS base[0], base[stride], ... (n <= CH of them, base in u64 units and 16-byte aligned)
+// until both halves of each carry `want` under `mask`.  One `global_load_dwordx4 sc1` per pair: the bypass-load path of a
+// CU moves ~10 B/clk however it is cut up, and 8-byte loads reach only 0.54-0.70x the 16-byte rate, so the sweep of the
+// whole exchange vector - not the latency of one load - sets the length of a polling round.  All CH loads of a round are
+// issued back to back (entries >= n re-read entry 0 and are not checked).  Inline asm because the loads must be re-issued
+// every round; the gather waves have nothing else in their vector-memory queue, so `s_waitcnt vmcnt(0)` is exact.
 template <int CH>
-__device__ __forceinline__ void poll_round(const u64* const (&a)[CH], u32x4 (&v)[CH]) {
-    static_assert(CH >= 1 && CH <= 10, "poll_round: add a case (one asm statement per width)");
-    if constexpr (CH == 1) {
-        asm volatile(G16_LD(0, 1) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0])
-                     : "v"(a[0]) : "memory");
-    } else if constexpr (CH == 2) {
-        asm volatile(G16_LD(0, 2) G16_LD(1, 3) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1])
-                     : "v"(a[0]), "v"(a[1]) : "memory");
-    } else if constexpr (CH == 3) {
-        asm volatile(G16_LD(0, 3) G16_LD(1, 4) G16_LD(2, 5) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]) : "memory");
-    } else if constexpr (CH == 4) {
-        asm volatile(G16_LD(0, 4) G16_LD(1, 5) G16_LD(2, 6) G16_LD(3, 7) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
-    } else if constexpr (CH == 5) {
-        asm volatile(G16_LD(0, 5) G16_LD(1, 6) G16_LD(2, 7) G16_LD(3, 8) G16_LD(4, 9) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]) : "memory");
-    } else if constexpr (CH == 6) {
-        asm volatile(G16_LD(0, 6) G16_LD(1, 7) G16_LD(2, 8) G16_LD(3, 9) G16_LD(4, 10) G16_LD(5, 11) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]) : "memory");
-    } else if constexpr (CH == 7) {
-        asm volatile(G16_LD(0, 7) G16_LD(1, 8) G16_LD(2, 9) G16_LD(3, 10) G16_LD(4, 11) G16_LD(5, 12) G16_LD(6, 13) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]) : "memory");
-    } else if constexpr (CH == 8) {
-        asm volatile(G16_LD(0, 8) G16_LD(1, 9) G16_LD(2, 10) G16_LD(3, 11) G16_LD(4, 12) G16_LD(5, 13) G16_LD(6, 14) G16_LD(7, 15) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
-    } else if constexpr (CH == 9) {
-        asm volatile(G16_LD(0, 9) G16_LD(1, 10) G16_LD(2, 11) G16_LD(3, 12) G16_LD(4, 13) G16_LD(5, 14) G16_LD(6, 15) G16_LD(7, 16) G16_LD(8, 17) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]) : "memory");
-    } else if constexpr (CH == 10) {
-        asm volatile(G16_LD(0, 10) G16_LD(1, 11) G16_LD(2, 12) G16_LD(3, 13) G16_LD(4, 14) G16_LD(5, 15) G16_LD(6, 16) G16_LD(7, 17) G16_LD(8, 18) G16_LD(9, 19) "s_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9])
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]) : "memory");
-    }
-}
-#undef G16_LD
-
-template <int CH>
-__device__ __forceinline__ bool poll_check(const u32x4 (&v)[CH], int n, u64 mask, u64 want, u64 (&lo)[CH], u64 (&hi)[CH]) {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        lo[i] = (u64)v[i][0] | ((u64)v[i][1] << 32);
-        hi[i] = (u64)v[i][2] | ((u64)v[i][3] << 32);
-        ok = ok && ((i >= n) || (((lo[i] & mask) == want) && ((hi[i] & mask) == want)));
-    }
-    return ok;
-}
-
-// Polls the 16-byte granule PAIRS addr[0..n) (n <= CH, 16-byte aligned) until both halves of each carry `want` under
-// `mask`.  One 16-byte load per pair: the bypass-load path of a CU moves ~10 B/clk however it is cut up, and 8-byte loads
-// reach only 0.54-0.70x the 16-byte rate, so the sweep of the whole exchange vector - not the latency of one load - sets
-// the length of a polling round.  Entries >= n re-read entry 0 and are not checked.
-template <int CH>
-__device__ __forceinline__ int gather16v(const u64* const (&addr)[CH], int n, u64 mask, u64 want, u64 (&lo)[CH], u64 (&hi)[CH],
-                                         unsigned* abort_flag) {
-    const u64* a[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) a[i] = addr[i < n ? i : 0];
+__device__ __forceinline__ int gather16(const u64* base, long stride, int n, u64 mask, u64 want, u64 (&lo)[CH], u64 (&hi)[CH],
+                                        unsigned* abort_flag) {
     int spins = 0;
     while (true) {
         u32x4 v[CH];
-        poll_round<CH>(a, v);
-        if (poll_check<CH>(v, n, mask, want, lo, hi)) return spins;
+        // the loads of a round and their wait in ONE asm statement where CH allows: between separate statements hipcc was
+        // seen to place an `s_waitcnt vmcnt(0)` of its own behind the first load (one extra round trip per round)
+        if constexpr (CH == 1) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(base) : "memory");
+        } else if constexpr (CH == 2) {
+            const u64* a1 = base + (1 < n ? 1 : 0) * stride;
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(base), "v"(a1) : "memory");
+        } else if constexpr (CH == 3) {
+            const u64* a1 = base + (1 < n ? 1 : 0) * stride;
+            const u64* a2 = base + (2 < n ? 2 : 0) * stride;
+            asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(base), "v"(a1), "v"(a2) : "memory");
+        } else if constexpr (CH == 5) {
+            const u64* a1 = base + (1 < n ? 1 : 0) * stride;
+            const u64* a2 = base + (2 < n ? 2 : 0) * stride;
+            const u64* a3 = base + (3 < n ? 3 : 0) * stride;
+            const u64* a4 = base + (4 < n ? 4 : 0) * stride;
+            asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                         "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(base), "v"(a1), "v"(a2), "v"(a3), "v"(a4) : "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const u64* a = base + (i < n ? i : 0) * stride;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(a) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // The destination registers of the loads above are only DEFINED for the compiler, not "complete": nothing tells it
+            // that their contents arrive at the s_waitcnt.  It is free to schedule the tag checks below - plain VALU reads of
+            // v[i] - in front of the wait statement, where the registers still hold the previous poll's data.  When that was the
+            // previous STEP's granule with the same step tag (steps 2k and 2k+1 share one) the check passed on stale registers
+            // and the not-yet-published slot (zeros) was consumed: the intermittent decoder deviations of round 2 (DESIGN.md
+            // section 2).  An empty volatile asm that "modifies" each register pins every later use behind the wait.
+            // WHY NOT ONE STATEMENT HERE TOO (round 3, measured): as a single asm with early-clobber outputs a 10-wide round
+            // needs its 40 destination and 20 address registers live at once; dec_bwd_persist then spills 216 registers instead
+            // of 41 (dec_fwd_persist: 126 -> 168 registers + scratch), the spill traffic shares the polling waves' in-order
+            // vector-memory queue, and the step lost 2.4 ms (17.7 -> 20.1; A/B in one gpurun call, profiles/r03_handoff_ab.txt).
+            // What the pins cannot exclude in principle - a register copy or spill of a destination placed between its load
+            // and the wait - is excluded on the BUILT code instead: tests/test_handoff_isa.py disassembles the objects of every
+            // kernel that polls and fails if any instruction touches a poll destination between its load and the wait.
+#pragma unroll
+            for (int i = 0; i < CH; ++i) asm volatile("" : "+v"(v[i]));
+        }
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            lo[i] = (u64)v[i][0] | ((u64)v[i][1] << 32);
+            hi[i] = (u64)v[i][2] | ((u64)v[i][3] << 32);
+            ok = ok && ((i >= n) || (((lo[i] & mask) == want) && ((hi[i] & mask) == want)));
+        }
+        if (ok) return spins;
         ++spins;
         if ((spins & 63) == 0) {
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return spins;
@@ -146,14 +126,40 @@ __device__ __forceinline__ int gather16v(const u64* const (&addr)[CH], int n, u6
     }
 }
 
-// The same for the strided pairs base[0], base[stride], ... (u64 units).
+
+// Same polling sweep with an explicit address per entry (entries >= n re-read entry 0 and are not checked).
 template <int CH>
-__device__ __forceinline__ int gather16(const u64* base, long stride, int n, u64 mask, u64 want, u64 (&lo)[CH], u64 (&hi)[CH],
-                                        unsigned* abort_flag) {
-    const u64* a[CH];
+__device__ __forceinline__ int gather16v(const u64* const (&addr)[CH], int n, u64 mask, u64 want, u64 (&lo)[CH], u64 (&hi)[CH],
+                                         unsigned* abort_flag) {
+    int spins = 0;
+    while (true) {
+        u32x4 v[CH];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) a[i] = base + (i < n ? i : 0) * stride;
-    return gather16v<CH>(a, n, mask, want, lo, hi, abort_flag);
+        for (int i = 0; i < CH; ++i) {
+            const u64* a = addr[i < n ? i : 0];
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < CH; ++i) asm volatile("" : "+v"(v[i]));        // uses of v[i] stay behind the wait (see gather16)
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            lo[i] = (u64)v[i][0] | ((u64)v[i][1] << 32);
+            hi[i] = (u64)v[i][2] | ((u64)v[i][3] << 32);
+            ok = ok && ((i >= n) || (((lo[i] & mask) == want) && ((hi[i] & mask) == want)));
+        }
+        if (ok) return spins;
+        ++spins;
+        if ((spins & 63) == 0) {
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return spins;
+            if (spins > SPIN_LIMIT2) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return spins;
+            }
+        }
+    }
 }
+
 
 }  // namespace

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libasr_hip.so')
+LIB_PATH = os.environ.get('ASR_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libasr_hip.so')      # ASR_HIP_LIB: A/B builds (tools/), never a fallback
 
 F32, BF16 = 0, 1
 DEBUG_KEEP = os.environ.get('ASR_DEBUG_KEEP', '0') == '1'      # layers keep references to their saved activations (tools/dbg_*.py)

@@ -1,7 +1,10 @@
 """ISA check of the hand-off polls (csrc/handoff.h::poll_round): in the BUILT code objects of the persistent kernels no
 instruction may touch a destination register of a polling `global_load_dwordx4 ... sc1` between that load and the
 `s_waitcnt vmcnt(0)` that completes it.  A read there would see the previous poll's data (the intermittent decoder
-deviation of round 2); a copy or a spill there would move stale data.  CPU-only: disassembles
+deviation of round 2); a copy or a spill there would move stale data.  The narrow polls (1, 2, 3, 5 loads)
+are one asm statement with early-clobber outputs, where this holds by construction; the wide ones (4, 6..10 loads) keep
+separate statements + register pins, because the one-statement form at 10 loads costs 175 spilled registers and 2.4 ms per
+training step (csrc/handoff.h) - for them this test IS the guarantee, on the code that ships.  CPU-only: disassembles
 lib/obj/*.o with the ROCm llvm-objdump."""
 import os
 import re
@@ -75,7 +78,7 @@ def scan(isa):
     return rounds, loads, bad
 
 
-@pytest.mark.parametrize('name,min_rounds', [('decoder_persist', 4), ('lstm_persist3', 4), ('lstm_persist2', 2)])
+@pytest.mark.parametrize('name,min_rounds', [('decoder_persist', 4), ('decoder_stream', 4), ('lstm_persist3', 4), ('lstm_persist2', 2)])
 def test_no_use_of_poll_destinations_before_the_wait(name, min_rounds, tmp_path):
     rounds, loads, bad = scan(device_isa(name, tmp_path))
     assert rounds >= min_rounds, (name, rounds)          # the check must have seen the polling loops

@@ -78,9 +78,13 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, co
 // torch.optim.Adam (L2 weight decay, optional amsgrad) with the same clip / NaN guard / status refusal in front
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, long n, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2_sqrt, float clip,
+                                                   float eps, float wd, int step_host, const unsigned long long* __restrict__ step_dev, float clip,
                                                    const double* __restrict__ normsq, float gmul, const unsigned* __restrict__ status) {
     if (status && *status != 0u) return;
+    // bias corrections in double (1 - beta^step in float32 is off by ~6e-5 relative at step 1); the step is the number of
+    // APPLIED updates so far + 1: with a device counter (step_dev) a refused update does not advance it, as in torch
+    const double stepd = step_dev ? (double)(*step_dev + 1ull) : (double)step_host;
+    const float bc1 = (float)(1.0 - pow((double)b1, stepd)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, stepd));
     float coef = gmul;
     if (normsq) {
         const double nrm = sqrt(*normsq) * (double)gmul;
@@ -103,6 +107,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = pi - step_size * (mi / denom);
     }
+}
+
+// advances the device-side count of applied Adam updates under exactly the guard of adam_kernel
+__global__ void adam_count_kernel(unsigned long long* step_dev, const double* __restrict__ normsq, float gmul, const unsigned* __restrict__ status) {
+    if (status && *status != 0u) return;
+    if (normsq) { const double nrm = sqrt(*normsq) * (double)gmul; if (!(nrm == nrm) || nrm == INFINITY) return; }
+    *step_dev = *step_dev + 1ull;
 }
 
 // ORs "abort word != 0" of up to 32 persistent-launch workspaces into the sticky status word
@@ -161,11 +172,12 @@ extern "C" int asr_status_collect(const void* const* abort_words, int n, unsigne
 
 extern "C" int asr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long n,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip,
-                             const double* normsq, float grad_mul, const unsigned* status, asr_stream_t stream) {
-    ASR_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, ASR_E_ARG, "asr_adam_step: bad args");
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+                             const double* normsq, float grad_mul, const unsigned* status, unsigned long long* step_counter,
+                             asr_stream_t stream) {
+    ASR_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && (step >= 1 || step_counter), ASR_E_ARG, "asr_adam_step: bad args");
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, n,
-                       lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), clip, normsq, grad_mul, status);
+                       lr, beta1, beta2, eps, weight_decay, step, (const unsigned long long*)step_counter, clip, normsq, grad_mul, status);
+    if (step_counter) hipLaunchKernelGGL(adam_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter, normsq, grad_mul, status);
     ASR_LAUNCH_CHECK("asr_adam_step");
     return ASR_OK;
 }

@@ -69,9 +69,12 @@ class Encoder(nn.Module):
         self.layers = nn.ModuleList(layers)
 
     def forward(self, input_x, enc_len, ctx=None):
-        if self.training and ctx is not None and input_x.is_cuda:
+        if ctx is not None and input_x.is_cuda:
+            H.begin_forward()
             # CU split between the recurrence stream and the side stream follows the widest recurrent layer of THIS model
+            # (eval-mode forwards are followed by backward passes too: tests, gradient checks)
             H.configure_rec_units([m.dim for m in self.layers if isinstance(m, RNNLayer)])
+        if self.training and ctx is not None and input_x.is_cuda:
             F_hip.prepack16([m for m in self.layers if isinstance(m, RNNLayer)], input_x.shape[0], ctx.prec)
         for layer in self.layers:
             input_x, enc_len = layer(input_x, enc_len, ctx)

@@ -91,7 +91,7 @@ SIGNATURES = {
     'asr_sumsq': [_vp, _l, _vp, _vp],
     'asr_scale': [_vp, _l, _f, _vp],
     'asr_adadelta_step': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp],
-    'asr_adam_step': [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _f, _vp, _vp],
+    'asr_adam_step': [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _f, _vp, _vp, _vp],
     'asr_embedding_bwd': [_vp, _l, _vp, _vp, _i, _i, _i, _vp],
     'asr_status_collect': [ctypes.POINTER(_vp), _i, _vp, _vp],
     'asr_beam_candidates': [_vp, _vp, _i, _i, _i, _vp],
@@ -506,6 +506,17 @@ def defer_side(fn, *tensors):
             _side['callback'] = True
         except RuntimeError:
             pass                      # not inside a backward pass: the caller joins explicitly
+
+
+def begin_forward():
+    """Called at the start of every model forward.  A backward pass that died with an exception leaves its deferred closures
+    and the 'engine callback registered' mark behind; the next backward would then neither register its join nor run its own
+    deferred parameter gradients (seen as wrong gradients of the first recurrent layer in the test AFTER a failing one).
+    No backward is in flight when a forward starts, so whatever is still queued here is stale."""
+    if _side['deferred'] or _side.get('callback'):
+        _side['deferred'] = []
+        _side['callback'] = False
+        del _side['keep'][:]
 
 
 def flush_side(after=None):

@@ -86,7 +86,9 @@ class HipAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.max_exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev) if amsgrad else None
         self.normsq = torch.zeros(1, dtype=torch.float64, device=dev)
-        self._steps = 0
+        # ONE device-side count of APPLIED updates (asr_adam_step advances it under the kernel's own guard: a refused update -
+        # abort status, NaN norm - does not move the bias corrections, as in torch); read back only where the host syncs anyway
+        self.steps_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         for p in allp:   # per-parameter views: state_dict() has torch.optim.Adam's layout
             o, k = self._offsets[id(p)], p.numel()
             self.state[p] = {'step': torch.tensor(0.0), 'exp_avg': self.exp_avg[o:o + k].view(p.shape),
@@ -98,31 +100,45 @@ class HipAdam(torch.optim.Optimizer):
         self.flat_grad.zero_()
 
     def grad_norm(self, grad_mul=1.0):
+        """As HipAdadelta.grad_norm: the ranges of requires_grad=False parameters are cleared first."""
+        for g in self.param_groups:
+            for p in g['params']:
+                if not p.requires_grad and p.grad is not None:
+                    p.grad.zero_()
         H.call('asr_sumsq', H.ptr(self.flat_grad), self.flat_grad.numel(), H.ptr(self.normsq), H.stream_ptr())
         return self.normsq
+
+    @property
+    def _steps(self):
+        return int(self.steps_dev.item())
 
     @torch.no_grad()
     def step(self, clip=0.0, grad_mul=1.0, use_norm=False):
         g = self.param_groups[0]
-        self._steps += 1
         H.call('asr_adam_step', H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.exp_avg), H.ptr(self.exp_avg_sq),
                H.ptr(self.max_exp_avg_sq), self.flat_param.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
-               float(g['eps']), float(g['weight_decay']), self._steps, float(clip), H.ptr(self.normsq) if use_norm else None,
-               float(grad_mul), H.ptr(H.collect_status()), H.stream_ptr())
+               float(g['eps']), float(g['weight_decay']), 0, float(clip), H.ptr(self.normsq) if use_norm else None,
+               float(grad_mul), H.ptr(H.collect_status()), H.ptr(self.steps_dev), H.stream_ptr())
+
+    def state_dict(self):
+        n = float(self._steps)                  # synchronises: checkpoints only
         for st in self.state.values():
-            st['step'] = torch.tensor(float(self._steps))
+            st['step'] = torch.tensor(n)
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        steps = 0
         for g in self.param_groups:
             for p in g['params']:
                 o, k = self._offsets[id(p)], p.numel()
                 st = self.state[p]
-                self._steps = max(self._steps, int(float(st.get('step', 0))))
+                steps = max(steps, int(float(st.get('step', 0))))
                 for name, flat in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq), ('max_exp_avg_sq', self.max_exp_avg_sq)):
                     if flat is not None and name in st:
                         flat[o:o + k].copy_(st[name].reshape(-1))
                         st[name] = flat[o:o + k].view(p.shape)
+        self.steps_dev.fill_(steps)
 
 
 class Optimizer():

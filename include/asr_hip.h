@@ -309,10 +309,12 @@ int asr_adadelta_step(float* param, const float* grad, float* square_avg, float*
                       float lr, float rho, float eps, float weight_decay, float clip,
                       const double* normsq, float grad_mul, const unsigned* status, asr_stream_t stream);
 /* torch.optim.Adam (the reference's LM trainer: /root/reference/bin/train_lm.py:38, src/optim.py:27-28) behind the same clip /
- * NaN guard / status refusal; `step` = 1-based update count for the bias corrections; max_exp_avg_sq: amsgrad state or NULL. */
+ * NaN guard / status refusal; bias corrections in double.  `step_counter` (device, may be NULL): number of updates APPLIED so
+ * far - the kernel uses *step_counter + 1 and the call advances it only when the update was applied (torch advances its step
+ * on applied steps only); with NULL, `step` = 1-based update count from the host.  max_exp_avg_sq: amsgrad state or NULL. */
 int asr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, long n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip,
-                  const double* normsq, float grad_mul, const unsigned* status, asr_stream_t stream);
+                  const double* normsq, float grad_mul, const unsigned* status, unsigned long long* step_counter, asr_stream_t stream);
 /* Embedding gradient (nn.Embedding backward of the RNN-LM, /root/reference/src/lm.py:16,28): demb[v,:] += sum of the rows r
  * of dy (rows x width, leading dimension dy_ld) with idx[r] == v; fixed summation order. */
 int asr_embedding_bwd(const float* dy, long dy_ld, const int64_t* idx, float* demb, int rows, int width, int V, asr_stream_t stream);

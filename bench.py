@@ -304,7 +304,8 @@ def main():
     log('timed %d steps in %.3f s' % (args.steps, dt))
     lstm_summ = timer.summary()
     post_steps = 3
-    timer.names, timer.records, timer.enabled = {'asr_att_decoder_fwd', 'asr_att_decoder_bwd', 'asr_att_decoder_bwd_ex', 'asr_att_decoder_bwd_params', 'asr_gemm', 'asr_gemm16'}, [], True
+    timer.names, timer.records, timer.enabled = {'asr_att_decoder_fwd', 'asr_att_decoder_bwd', 'asr_att_decoder_bwd_ex', 'asr_att_decoder_bwd_params', 'asr_gemm', 'asr_gemm16',
+                                                    'asr_conv3x3', 'asr_conv3x3_16', 'asr_conv3x3_16_wgrad'}, [], True
     for _ in range(post_steps):
         step()
     torch.cuda.synchronize()
@@ -379,6 +380,22 @@ def main():
                 'ms_per_step': gsec * 1e3 / post_steps, 'gflop_per_step': flop / post_steps / 1e9,
                 'measured': '%d steps after the timed region' % post_steps,
                 }
+    # ---- the VGG convolutions (vgg 1 / vgg 5 workloads): implicit GEMMs, 2 * pixels * N * 9C flop per call, against the same peak
+    conv = None
+    ccalls = post_summ.get('asr_conv3x3', []) + post_summ.get('asr_conv3x3_16', []) + post_summ.get('asr_conv3x3_16_wgrad', [])
+    if ccalls:
+        cflop = 0.0
+        for a, _ in post_summ.get('asr_conv3x3', []):            # (img, w, out, bias, B, T, F, Ci, Co, mode, ...)
+            cflop += 2.0 * a[4] * a[5] * a[6] * a[7] * a[8] * 9
+        for a, _ in post_summ.get('asr_conv3x3_16', []):         # (img, w, out, bias, B, T, F, C, N, K, implicit, ...): bordered pixel grid
+            cflop += 2.0 * a[4] * (a[5] + 2) * (a[6] + 2) * a[8] * a[9]
+        for a, _ in post_summ.get('asr_conv3x3_16_wgrad', []):   # (img, dout, dw, B, T, F, C, N, ...)
+            cflop += 2.0 * a[3] * (a[4] + 2) * (a[5] + 2) * a[6] * a[7] * 9
+        csec = sum(ms for _, ms in ccalls) * 1e-3
+        conv = {'kernel': 'VGG 3x3 convolutions: gemm16_nt_kernel<2,2,4,CONV> (implicit GEMM on zero-bordered bf16 images) forward + input gradient, '
+                          'gemm16_tn_kernel with the tap as a grid dimension for the weight gradient (fp32 mode / uncovered shapes: gemm_kernel)',
+                'bound': 'mfma', 'achieved': cflop / csec / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': cflop / csec / 1e12 / 2500.0,
+                'calls_per_step': len(ccalls) / post_steps, 'ms_per_step': csec * 1e3 / post_steps, 'gflop_per_step': cflop / post_steps / 1e9}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         log('cpu baseline (oracle) for ~%.0f s...' % args.cpu_seconds)
@@ -394,8 +411,8 @@ def main():
         'valid_frames_per_s': valid / dt, 'loss': loss, 'per_rank_ms_per_step': per_rank_ms,
         'per_rank_frames': [frames // world] * world, 'per_rank_max_T': [max(int(bt[0].shape[1]) for bt in batches)] * world, 'host_enqueue_ms_per_step': t_host / args.steps * 1e3,
         'stage_ms_per_step': dict([(k, v / args.steps) for k, v in tot.items()] +
-                                  [(k, sum(ms for _, ms in v) / post_steps) for k, v in post_summ.items() if k not in ('asr_gemm', 'asr_gemm16')]),
-        'roofline': roof, 'roofline_gemm': gemm, 'cpu_baseline': cpu,
+                                  [(k, sum(ms for _, ms in v) / post_steps) for k, v in post_summ.items() if k not in ('asr_gemm', 'asr_gemm16', 'asr_conv3x3', 'asr_conv3x3_16', 'asr_conv3x3_16_wgrad')]),
+        'roofline': roof, 'roofline_gemm': gemm, 'roofline_conv': conv, 'cpu_baseline': cpu,
     }
     if args.host_input:
         line['input'] = 'pinned host memory, copied to the GPU inside every step (PCIe-inclusive; not the headline value)'

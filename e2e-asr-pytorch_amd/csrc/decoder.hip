@@ -905,66 +905,72 @@ __global__ __launch_bounds__(256) void wconv_grad_mfma_kernel(DecP p, float* __r
     const int taps = 2 * d.Ks + 1;
     const int ntile = (taps + 15) >> 4;                   // 16-tap output tiles
     const int len = min((int)p.enc_len[b], d.Tp);
-    const int nchunk = (len + 31) >> 5, TpP = 32 * ((d.Tp + 31) >> 5);
-    const int wpa = TpP + 16 * ntile + 16;
-    float* s_pa = smem_f;                                // [TpP + 16*ntile + 16]  zero-padded previous attention: s_pa[i] = att[i - Ks]
-    float* s_dc = s_pa + ((wpa + 3) & ~3);               // [16][TpP]  dconv rows, zero beyond Kn / len
+    // frames are walked in segments of <= 768 (one LDS image of the dconv rows and of the attention window per segment), so any
+    // T' is covered (round 2 took this kernel only up to T' = 768 and fell back to the VALU kernel beyond: 14 ms at config 5)
+    const int TpP = 32 * ((d.Tp + 31) >> 5);
+    const int SEG = min(TpP, 768);
+    const int wpa = SEG + 16 * ntile + 16;
+    float* s_pa = smem_f;                                // [SEG + 16*ntile + 16]  zero-padded previous attention: s_pa[i] = att[seg + i - Ks]
+    float* s_dc = s_pa + ((wpa + 3) & ~3);               // [16][SEG]  dconv rows of the segment, zero beyond Kn / len
     constexpr int MAXT = 4;                              // tiles per wave (taps <= 256)
     f32x4 acc[MAXT];
 #pragma unroll
     for (int u = 0; u < MAXT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int m = lane & 15, q = lane >> 4;
     for (int l = blockIdx.x; l < d.L; l += gridDim.x) {
-        __syncthreads();
         const float* prev = (l > 0) ? p.s.att + ((long)b * d.L + (l - 1)) * d.Tp : nullptr;
         const float uni = 1.f / (float)max(len, 1);
-        // staging with all loads of a batch in flight (clamped addresses, zeroing by selects): T' <= 768, wpa <= 1024
-        {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tau = tid + 256 * j - d.Ks;
-                v[j] = prev ? prev[min(max(tau, 0), d.Tp - 1)] : uni;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = tid + 256 * j, tau = i - d.Ks;
-                if (i < wpa) s_pa[i] = (tau >= 0 && tau < (prev ? d.Tp : len)) ? v[j] : 0.f;
-            }
-        }
         const float* dconv = p.s.conv + ((long)b * d.L + l) * d.Kn * d.Tp;
-#pragma unroll 1
-        for (int k0 = 0; k0 < 16; k0 += 4) {
-            float v[4][3];
+        for (int seg = 0; seg < len; seg += SEG) {
+            __syncthreads();
+            // staging with all loads of a batch in flight (clamped addresses, zeroing by selects): SEG <= 768, wpa <= 1024
+            {
+                float v[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    v[kk][j] = dconv[(long)min(k0 + kk, d.Kn - 1) * d.Tp + min(tid + 256 * j, d.Tp - 1)];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int tau = tid + 256 * j;
-                    if (tau < TpP) s_dc[(k0 + kk) * TpP + tau] = (k0 + kk < d.Kn && tau < len) ? v[kk][j] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int tau = seg + tid + 256 * j - d.Ks;
+                    v[j] = prev ? prev[min(max(tau, 0), d.Tp - 1)] : uni;
                 }
-        }
-        __syncthreads();
-        for (int c = 0; c < nchunk; ++c) {
-            const float* ar = s_dc + m * TpP + 32 * c + 8 * q;
-            const float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 4);
-            bf16x8 av;
-            av[0] = (__bf16)a0.x; av[1] = (__bf16)a0.y; av[2] = (__bf16)a0.z; av[3] = (__bf16)a0.w;
-            av[4] = (__bf16)a1.x; av[5] = (__bf16)a1.y; av[6] = (__bf16)a1.z; av[7] = (__bf16)a1.w;
 #pragma unroll
-            for (int u = 0; u < MAXT; ++u) {
-                const int tile = wave + 4 * u;
-                if (tile < ntile) {
-                    const float* br = s_pa + 32 * c + 8 * q + 16 * tile + m;      // pa[tau + j], tau = 32c + 8q + e, j = 16*tile + m
-                    bf16x8 bv;
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + 256 * j, tau = seg + i - d.Ks;
+                    if (i < wpa) s_pa[i] = (tau >= 0 && tau < (prev ? d.Tp : len)) ? v[j] : 0.f;
+                }
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < 16; k0 += 4) {
+                float v[4][3];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bv[e] = (__bf16)br[e];
-                    acc[u] = mma16(av, bv, acc[u]);
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        v[kk][j] = dconv[(long)min(k0 + kk, d.Kn - 1) * d.Tp + min(seg + tid + 256 * j, d.Tp - 1)];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int ti = tid + 256 * j;
+                        if (ti < SEG) s_dc[(k0 + kk) * SEG + ti] = (k0 + kk < d.Kn && seg + ti < len) ? v[kk][j] : 0.f;
+                    }
+            }
+            __syncthreads();
+            const int nchunk = (min(len - seg, SEG) + 31) >> 5;
+            for (int c = 0; c < nchunk; ++c) {
+                const float* ar = s_dc + m * SEG + 32 * c + 8 * q;
+                const float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 4);
+                bf16x8 av;
+                av[0] = (__bf16)a0.x; av[1] = (__bf16)a0.y; av[2] = (__bf16)a0.z; av[3] = (__bf16)a0.w;
+                av[4] = (__bf16)a1.x; av[5] = (__bf16)a1.y; av[6] = (__bf16)a1.z; av[7] = (__bf16)a1.w;
+#pragma unroll
+                for (int u = 0; u < MAXT; ++u) {
+                    const int tile = wave + 4 * u;
+                    if (tile < ntile) {
+                        const float* br = s_pa + 32 * c + 8 * q + 16 * tile + m;      // pa[tau + j], tau = seg + 32c + 8q + e, j = 16*tile + m
+                        bf16x8 bv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bv[e] = (__bf16)br[e];
+                        acc[u] = mma16(av, bv, acc[u]);
+                    }
                 }
             }
         }
@@ -1619,9 +1625,9 @@ extern "C" int asr_att_decoder_bwd_params(const asr_dec_dims_t* dims, const asr_
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(cdiv(d.A * d.Kn, 4)), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->Wproj, d.A, d.A * d.Kn, d.A, d.Kn);
     hipLaunchKernelGGL(slot_reduce_kernel, dim3(1), dim3(256), 0, st, p.slots, nslots, lay.slot, grads->bg, d.A * (1 + d.Kn), 1, 0, 0);
     {
-        const int ntile = (taps + 15) / 16, TpP = 32 * cdiv(d.Tp, 32);
-        const size_t lds_m = sizeof(float) * ((size_t)((TpP + 16 * ntile + 16 + 3) & ~3) + (size_t)16 * TpP);
-        if (bf && d.Kn <= 16 && ntile <= 16 && lds_m <= 150 * 1024 && TpP <= 768 && TpP + 16 * ntile + 16 <= 1024) {
+        const int ntile = (taps + 15) / 16, SEG = std::min(32 * cdiv(d.Tp, 32), 768);
+        const size_t lds_m = sizeof(float) * ((size_t)((SEG + 16 * ntile + 16 + 3) & ~3) + (size_t)16 * SEG);
+        if (bf && d.Kn <= 16 && ntile <= 16 && lds_m <= 150 * 1024 && SEG + 16 * ntile + 16 <= 1024) {
             static bool attr_m = false;
             if (!attr_m) { hipFuncSetAttribute((const void*)wconv_grad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr_m = true; }
             hipLaunchKernelGGL(wconv_grad_mfma_kernel, dim3(lay.nch, d.B), dim3(256), lds_m, st, p.f, wslots);

@@ -30,6 +30,10 @@ struct G16P {
     int act;
     unsigned xbytes, wbytes;
     int ntx, nty;            // tiles along N, along M
+    // CONV instantiation only: rows are the pixels of a zero-bordered channel-last image (B, T2, F2, C) and k-step kt of the
+    // 9*C-deep reduction reads the rows shifted by its tap (convC > 0), border rows are stored as zeros (maskF2 > 0)
+    int convC, maskF2, maskT2;
+    float* C32;              // CONV only: when set, the result goes here as fp32 (pre-activations that a LayerNorm normalises next)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -41,7 +45,7 @@ __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __built
 //   <2,4,8>  256 x 256, 512 threads, 2 x 64 KB LDS, one workgroup per CU - a wave's 128 x 64 block reads 12 fragments for
 //            32 MFMAs (8 for 16 in the small tiling, where the LDS read port is as busy as the MFMA pipe: 64 KB of fragment
 //            reads = 512 clk per 512 clk of MFMA) and the L2 -> LDS bytes per flop are halved.
-template <int NWM, int NWN, int MT>
+template <int NWM, int NWN, int MT, bool CONV = false>
 __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN > 4) ? 1 : 2) void gemm16_nt_kernel(G16P p) {
     constexpr int BM = NWM * MT * 16, BN = NWN * 64, NW = NWM * NWN;
     constexpr int XP = BM / 8 / NW, WP = BN / 8 / NW;          // 8-row staging pieces per wave and operand
@@ -97,9 +101,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN > 4) ? 1 : 2) void gemm1
         const int k0 = kt * BK;
         const bool kok = (k0 + kchunk) < p.K;
         unsigned char* base = smem + buf * STAGE_BYTES;
+        // implicit 3x3 convolution: this k-step lies inside ONE tap (C % 64 == 0); its rows are the pixel rows shifted by
+        // (dt, df) in the zero-bordered image, i.e. by a constant number of rows - a negative total offset wraps to a huge
+        // unsigned value and the load returns zeros like any other access past num_records
+        unsigned kadd = (unsigned)(k0 * 2);
+        if (CONV && p.convC > 0) {
+            const int tap = k0 / p.convC, ci0 = k0 - tap * p.convC;
+            const int rowoff = (tap / 3 - 1) * p.maskF2 + (tap % 3 - 1);
+            kadd = (unsigned)(((long)rowoff * p.convC + ci0) * 2);
+        }
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const unsigned vx = (xoff[i] != OOB && kok) ? xoff[i] + (unsigned)(k0 * 2) : OOB;
+            const unsigned vx = (xoff[i] != OOB && kok) ? xoff[i] + kadd : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + (XP * w + i) * 1024), 16, vx, 0, 0, 0);
         }
 #pragma unroll
@@ -155,6 +168,21 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN > 4) ? 1 : 2) void gemm1
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
             const int m = m0 + wr * (16 * MT) + 16 * b + fr;
+            bool border = false;
+            if (CONV && p.maskF2 > 0) {
+                const int rowi = m / p.maskF2, fp = m - rowi * p.maskF2, tp = rowi % p.maskT2;
+                border = fp == 0 || fp == p.maskF2 - 1 || tp == 0 || tp == p.maskT2 - 1;
+            }
+            if (CONV && p.C32) {
+                // fp32 result (no activation): four consecutive columns per lane and tile
+                if (m < p.M) {
+                    if (na < p.N) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc + na) = border ? make_float4(0.f, 0.f, 0.f, 0.f) :
+                        make_float4(acc[a][b][0] + bva.x, acc[a][b][1] + bva.y, acc[a][b][2] + bva.z, acc[a][b][3] + bva.w);
+                    if (nb_ < p.N) *reinterpret_cast<float4*>(p.C32 + (long)m * p.ldc + nb_) = border ? make_float4(0.f, 0.f, 0.f, 0.f) :
+                        make_float4(acc[a + 1][b][0] + bvb.x, acc[a + 1][b][1] + bvb.y, acc[a + 1][b][2] + bvb.z, acc[a + 1][b][3] + bvb.w);
+                }
+                continue;
+            }
             unsigned oa[2], ob[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -168,7 +196,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN > 4) ? 1 : 2) void gemm1
             const auto s0 = __builtin_amdgcn_permlane16_swap(oa[0], ob[0], false, false);
             const auto s1 = __builtin_amdgcn_permlane16_swap(oa[1], ob[1], false, false);
             // rows 0,2 keep tile a's own words and receive its neighbour row's; rows 1,3 hold tile a+1 likewise
-            const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (CONV && border) o = make_uint4(0u, 0u, 0u, 0u);
             if (m < p.M && nst < p.N) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + nst) = o;
         }
     }
@@ -190,7 +219,7 @@ int gemm16_nt(const void* X, const void* W, void* C, const float* bias, int M, i
     static const bool big = [] { const char* e = getenv("ASR_GEMM16_BIG"); return e && atoi(e) > 0; }();
     const int bm = big ? 256 : BM, bn = big ? 256 : BN;
     G16P p{(const unsigned short*)X, (const unsigned short*)W, (unsigned short*)C, bias, M, N, K, ldx, ldw, ldc, act,
-           (unsigned)xb, (unsigned)wb, cdiv(N, bn), cdiv(M, bm)};
+           (unsigned)xb, (unsigned)wb, cdiv(N, bn), cdiv(M, bm), 0, 0, 0, nullptr};
     const long ntiles = (long)p.ntx * p.nty;
     if (ntiles >= (1L << 31)) return 1;
     if (big) {
@@ -205,6 +234,33 @@ int gemm16_nt(const void* X, const void* W, void* C, const float* bias, int M, i
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { asr_set_error("asr_gemm16(nt): launch failed: %s", hipGetErrorString(e)); return ASR_E_LAUNCH; }
+    return ASR_OK;
+}
+
+// 3x3 convolution (stride 1, zero padding 1) as an implicit GEMM on the NT kernel, nn.Conv2d of the VGG front-ends (reference
+// src/module.py:599-614,670-681).  img: zero-bordered channel-last bf16 image (B, T+2, F+2, C); W: (N, 9*C) bf16 with
+// k = tap*C + ci; out: (B, T+2, F+2, N) bf16, borders written as zeros (ready to be the next layer's input).  C % 64 == 0.
+// out_f32: the result is stored as fp32 (B, T+2, F+2, N) without activation (the input of a CNNLayerNorm).
+// convC == 0: `img` is an explicit (rows, K) patch matrix over the same zero-bordered pixel grid (first layer: C = 4), only the
+// border mask applies.  Returns 1 when the shape does not qualify.
+int gemm16_conv3x3(const void* img, const void* W, void* out, const float* bias, int B, int T, int F, int C, int N, int K, int implicit, int act,
+                   int out_f32, hipStream_t st) {
+    const int T2 = T + 2, F2 = F + 2;
+    const long M = (long)B * T2 * F2;
+    const long ldx = implicit ? C : K;
+    if (implicit && (C % 64 != 0 || K != 9 * C)) return 1;
+    if (K % 8 != 0 || N % 8 != 0 || M >= (1L << 31)) return 1;
+    if ((((uintptr_t)img | (uintptr_t)W | (uintptr_t)out) & 15) != 0 || (bias && ((uintptr_t)bias & 15) != 0)) return 1;
+    const long xb = M * ldx * 2, wb = (long)N * K * 2;
+    if (xb + 2L * K >= (long)OOB || wb + 2L * K >= (long)OOB) return 1;
+    G16P p{(const unsigned short*)img, (const unsigned short*)W, (unsigned short*)out, bias, (int)M, N, K, ldx, (long)K, (long)N, act,
+           (unsigned)xb, (unsigned)wb, cdiv(N, BN), cdiv(M, BM), implicit ? C : 0, F2, T2, out_f32 ? (float*)out : nullptr};
+    if (out_f32 && act != ASR_ACT_NONE) return 1;
+    const long ntiles = (long)p.ntx * p.nty;
+    if (ntiles >= (1L << 31)) return 1;
+    hipLaunchKernelGGL((gemm16_nt_kernel<2, 2, 4, true>), dim3((unsigned)ntiles), dim3(NTH), 2 * STAGE_BYTES, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { asr_set_error("asr_conv3x3_16: launch failed: %s", hipGetErrorString(e)); return ASR_E_LAUNCH; }
     return ASR_OK;
 }
 
@@ -229,6 +285,8 @@ struct T16P {
     int nti, ntj, splits, per;   // tiles along I and J, reduction slices, k-steps per slice
     int seqT, bshift, permH;
     float inv_seqT;
+    int tapF2;                   // > 0: NINE contractions in one launch, the taps of a 3x3 convolution's weight gradient: tap
+                                 // (dt, df) reads B at row r + dt*tapF2 + df (rows outside [0, R) are zeros) and writes C at column tap*J
 };
 
 __device__ __forceinline__ int swz_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
@@ -238,13 +296,16 @@ __global__ __launch_bounds__(NTH, 3) void gemm16_tn_kernel(T16P p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = p.nti * p.ntj;
-    const int total = ntiles * p.splits;
+    const int ntap = p.tapF2 > 0 ? 9 : 1;
+    const int total = ntiles * p.splits * ntap;
     int id = blockIdx.x;
     {
         const int qq = total >> 3, rr = total & 7, xcd = id & 7, loc = id >> 3;
         id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + loc;
     }
-    const int z = id / ntiles, tile = id - z * ntiles;
+    const int zt = id / ntiles, tile = id - zt * ntiles;
+    const int tap = zt % ntap, z = zt / ntap;
+    const int rowshift = p.tapF2 > 0 ? (tap / 3 - 1) * p.tapF2 + (tap % 3 - 1) : 0;
     const int bj = tile % p.ntj, bi = tile / p.ntj;
     const int i0 = bi * BM, j0 = bj * BN;
     const int nk = (p.R + BK - 1) / BK;
@@ -291,8 +352,9 @@ __global__ __launch_bounds__(NTH, 3) void gemm16_tn_kernel(T16P p) {
                 if (q * p.seqT > r) --q; else if ((q + 1) * p.seqT <= r) ++q;
                 rsrc = (long)r + 2 * q + 1 + p.bshift;
             }
+            if (p.tapF2 > 0) rsrc = (long)r + rowshift;
             const unsigned va = (rok && caok[i]) ? (unsigned)(((long)r * p.lda + colA[i]) * 2) : OOB;
-            const unsigned vb = (rok && cbok[i]) ? (unsigned)((rsrc * p.ldb + colB[i]) * 2) : OOB;
+            const unsigned vb = (rok && cbok[i] && rsrc >= 0 && (p.tapF2 == 0 || rsrc < p.R)) ? (unsigned)((rsrc * p.ldb + colB[i]) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + (4 * w + i) * 1024), 16, va, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + BK * 256 + (4 * w + i) * 1024), 16, vb, 0, 0, 0);
         }
@@ -340,15 +402,21 @@ __global__ __launch_bounds__(NTH, 3) void gemm16_tn_kernel(T16P p) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int j = j0 + wc * 64 + 16 * b + fr;
-                if (j < p.J) atomicAdd(p.C + (long)i * p.ldc + j, acc[a][b][r]);
+                if (j < p.J) atomicAdd(p.C + (long)i * p.ldc + (long)tap * p.J + j, acc[a][b][r]);
             }
         }
     }
 }
 
 // Returns ASR_OK when launched, 1 when the shape does not qualify.
+int gemm16_tn_taps(const void* A, const void* B, float* C, int I, int J, int R, long lda, long ldb, long ldc, int splits, int perm_h,
+                   int seqT, int bshift, int padded, int tapF2, hipStream_t st);
 int gemm16_tn(const void* A, const void* B, float* C, int I, int J, int R, long lda, long ldb, long ldc, int splits, int perm_h,
               int seqT, int bshift, int padded, hipStream_t st) {
+    return gemm16_tn_taps(A, B, C, I, J, R, lda, ldb, ldc, splits, perm_h, seqT, bshift, padded, 0, st);
+}
+int gemm16_tn_taps(const void* A, const void* B, float* C, int I, int J, int R, long lda, long ldb, long ldc, int splits, int perm_h,
+                   int seqT, int bshift, int padded, int tapF2, hipStream_t st) {
     if (I % 8 != 0 || J % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) return 1;
     if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return 1;
     if (seqT > 0 && !padded) return 1;                        // unpadded shifted rows need masking: generic kernel
@@ -359,8 +427,8 @@ int gemm16_tn(const void* A, const void* B, float* C, int I, int J, int R, long 
     if (splits < 1) splits = 1;
     if (splits > nk) splits = nk;
     T16P p{(const unsigned short*)A, (const unsigned short*)B, C, I, J, R, lda, ldb, ldc, (unsigned)ab, (unsigned)bb,
-           cdiv(I, BM), cdiv(J, BN), splits, cdiv(nk, splits), seqT, bshift, perm_h, seqT > 0 ? 1.0f / (float)seqT : 0.f};
-    const long total = (long)p.nti * p.ntj * p.splits;
+           cdiv(I, BM), cdiv(J, BN), splits, cdiv(nk, splits), seqT, bshift, perm_h, seqT > 0 ? 1.0f / (float)seqT : 0.f, tapF2};
+    const long total = (long)p.nti * p.ntj * p.splits * (tapF2 > 0 ? 9 : 1);
     if (total >= (1L << 31)) return 1;
     hipLaunchKernelGGL(gemm16_tn_kernel, dim3((unsigned)total), dim3(NTH), STAGE_BYTES, st, p);
     hipError_t e = hipGetLastError();

@@ -77,6 +77,17 @@ SIGNATURES = {
     'asr_specaug_ws': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u64, _vp, _sz, _vp],
     'asr_conv3x3': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     'asr_conv_weight_permute': [_vp, _vp, _i, _i, _i, _vp],
+    'asr_vgg16_im2col': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'asr_conv_weight_pack16': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'asr_conv_weight_fold': [_vp, _vp, _i, _i, _i, _vp],
+    'asr_conv3x3_16': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'asr_conv3x3_16_wgrad': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    'asr_maxpool2x2_16_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'asr_maxpool2x2_16_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    'asr_ln_freq16_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    'asr_ln_freq16_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'asr_vgg16_output': [_vp, _vp, _i, _i, _i, _i, _vp],
+    'asr_vgg16_output_bwd': [_vp, _vp, _i, _i, _i, _i, _vp],
     'asr_maxpool2x2_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'asr_maxpool2x2_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'asr_ln_freq_fwd': [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp],

@@ -113,6 +113,135 @@ class _VGGFn(torch.autograd.Function):
         return None, None, None, None
 
 
+def _b16(shape, dev):
+    return torch.empty(shape, dtype=torch.bfloat16, device=dev)
+
+
+def vgg16_ok(mod, prec):
+    """The bf16 front-end (csrc/vgg16.hip) covers bf16 contraction mode with channel counts that are multiples of 64 behind the
+    first layer (both reference extractors: 128/256 and 64/128) and at most 4 input channels per tap group (9*Cin <= 40)."""
+    import os
+    if prec != H.BF16 or os.environ.get('ASR_VGG16', '1') == '0':
+        return False
+    return mod.init_dim % 64 == 0 and mod.hide_dim % 64 == 0 and 9 * mod.in_channel <= 40
+
+
+class _VGG16Fn(torch.autograd.Function):
+    """The VGG front-end on zero-bordered channel-last bf16 images P(T,F,C) = (B, T+2, F+2, C): every convolution is an implicit
+    GEMM on the direct-to-LDS bf16 contraction kernel (asr_conv3x3_16), the weight gradient one launch of nine shifted-row TN
+    contractions, pooling / CNNLayerNorm / layout changes run on the bordered images (reference src/module.py:582-716)."""
+
+    @staticmethod
+    def forward(ctx, anchor, feature, mod, prec):
+        st = H.stream_ptr()
+        dev = feature.device
+        if feature.shape[1] % 4 != 0:
+            feature = feature[:, :-(feature.shape[1] % 4), :]
+        feature = feature.contiguous().float()
+        B, T, _ = feature.shape
+        Cin, F = mod.in_channel, mod.freq_dim
+        K1p = (9 * Cin + 7) // 8 * 8
+        sv = {'x': [], 'act': [], 'pre': [], 'stats': [], 'pool': [], 'dims': []}
+        cur, t, f = None, T, F
+        for li, (conv, ln) in enumerate(mod.conv_layers()):
+            Co, Ci = conv.weight.shape[0], conv.weight.shape[1]
+            Mp = B * (t + 2) * (f + 2)
+            f32 = 0 if ln is None else 1           # pre-activations of a CNNLayerNorm stay fp32 (see asr_conv3x3_16)
+            out = _b16((Mp, Co), dev) if ln is None else _e((Mp, Co), dev)
+            act_code = H.ACT_RELU if ln is None else H.ACT_NONE
+            if li == 0:
+                x1 = _b16((Mp, K1p), dev)
+                H.call('asr_vgg16_im2col', H.ptr(feature), H.ptr(x1), B, t, f, Cin, K1p, st)
+                w16 = _b16((Co, K1p), dev)
+                H.call('asr_conv_weight_pack16', H.ptr(conv.weight), H.ptr(w16), Co, Ci, K1p, 0, st)
+                H.call('asr_conv3x3_16', H.ptr(x1), H.ptr(w16), H.ptr(out), H.ptr(conv.bias), B, t, f, Ci, Co, K1p, 0, act_code, f32, st)
+                sv['x'].append(x1)
+            else:
+                w16 = _b16((Co, 9 * Ci), dev)
+                H.call('asr_conv_weight_pack16', H.ptr(conv.weight), H.ptr(w16), Co, Ci, 9 * Ci, 0, st)
+                H.call('asr_conv3x3_16', H.ptr(cur), H.ptr(w16), H.ptr(out), H.ptr(conv.bias), B, t, f, Ci, Co, 9 * Ci, 1, act_code, f32, st)
+                sv['x'].append(cur)
+            sv['dims'].append((t, f, Ci, Co))
+            if ln is None:
+                act = out
+                sv['pre'].append(None); sv['stats'].append(None)
+            else:
+                act = _b16((Mp, Co), dev)
+                stats = _e((B * (t + 2) * Co, 2), dev)
+                H.call('asr_ln_freq16_fwd', H.ptr(out), H.ptr(ln.weight), H.ptr(ln.bias), H.ptr(act), H.ptr(stats), B, t, f, Co, 1e-5, 1, st)
+                sv['pre'].append(out); sv['stats'].append(stats)
+            sv['act'].append(act)
+            if li in (1, 3):
+                t2, f2 = ((t + 1) // 2, (f + 1) // 2) if mod.ceil_mode else (t // 2, f // 2)
+                Mp2 = B * (t2 + 2) * (f2 + 2)
+                pooled = _b16((Mp2, Co), dev)
+                idx = torch.empty((Mp2, Co), dtype=torch.uint8, device=dev)
+                H.call('asr_maxpool2x2_16_fwd', H.ptr(act), H.ptr(pooled), H.ptr(idx), B, t, f, Co, t2, f2, st)
+                sv['pool'].append((idx, t, f, t2, f2))
+                cur, t, f = pooled, t2, f2
+            else:
+                sv['pool'].append(None)
+                cur = act
+        Co = cur.shape[-1]
+        out = _b16((B, t, Co * f), dev)
+        H.call('asr_vgg16_output', H.ptr(cur), H.ptr(out), B, t, f, Co, st)
+        ctx.mod, ctx.saved, ctx.B, ctx.final, ctx.K1p = mod, sv, B, (t, f, Co), K1p
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, sv, B, K1p = ctx.mod, ctx.saved, ctx.B, ctx.K1p
+        st = H.stream_ptr()
+        dev = dout.device
+        t, f, Co = ctx.final
+        dout = dout.contiguous()
+        if dout.dtype != torch.bfloat16:
+            d16 = _b16(tuple(dout.shape), dev)
+            H.call('asr_cast_bf16', H.ptr(dout), H.ptr(d16), dout.numel(), st)
+            dout = d16
+        g = _b16((B * (t + 2) * (f + 2), Co), dev)
+        H.call('asr_vgg16_output_bwd', H.ptr(dout), H.ptr(g), B, t, f, Co, st)
+        layers = list(mod.conv_layers())
+        for li in range(len(layers) - 1, -1, -1):
+            conv, ln = layers[li]
+            t_l, f_l, Ci, Co = sv['dims'][li]
+            Mp = B * (t_l + 2) * (f_l + 2)
+            if sv['pool'][li] is not None:
+                idx, tt, ff, t2, f2 = sv['pool'][li]
+                gp = _b16((Mp, Co), dev)
+                H.call('asr_maxpool2x2_16_bwd', H.ptr(g), H.ptr(idx), H.ptr(gp), B, tt, ff, Co, t2, f2, st)
+                g = gp
+            dpre = _b16((Mp, Co), dev)
+            if ln is None:
+                H.call('asr_act_bwd16', H.ptr(g), H.ptr(sv['act'][li]), H.ptr(dpre), Mp * Co, H.ACT_RELU, st)
+            else:
+                H.call('asr_ln_freq16_bwd', H.ptr(g), H.ptr(sv['pre'][li]), H.ptr(ln.weight), H.ptr(ln.bias), H.ptr(sv['stats'][li]),
+                       H.ptr(dpre), H.ptr(ln.weight.grad), H.ptr(ln.bias.grad), H.ptr(conv.bias.grad), B, t_l, f_l, Co, 1, st)
+            xin = sv['x'][li]
+            if li == 0:
+                dwf = torch.zeros((Co, K1p), dtype=torch.float32, device=dev)
+                H.gemm16(dpre, xin, dwf, Co, K1p, Mp, Co, K1p, K1p, 0, 0, accum=1, splits=min(64, max(1, Mp // 4096)))
+                H.call('asr_conv_weight_fold', H.ptr(dwf), H.ptr(conv.weight.grad), Co, Ci, K1p, st)
+            else:
+                dwf = torch.zeros((Co, 9 * Ci), dtype=torch.float32, device=dev)
+                tiles = ((Co + 127) // 128) * ((Ci + 127) // 128)
+                splits = max(1, min(Mp // 2048, 96 // tiles))          # x 9 taps: ~800 workgroups per launch
+                H.call('asr_conv3x3_16_wgrad', H.ptr(xin), H.ptr(dpre), H.ptr(dwf), B, t_l, f_l, Ci, Co, 9 * Ci, splits, st)
+                H.call('asr_conv_weight_fold', H.ptr(dwf), H.ptr(conv.weight.grad), Co, Ci, 9 * Ci, st)
+            if ln is None:         # (behind a CNNLayerNorm the bias gradient comes out of asr_ln_freq16_bwd, in fp32)
+                H.call('asr_colsum16', H.ptr(dpre), Co, Mp, Co, H.ptr(conv.bias.grad), None, 0, st)
+            if li > 0:
+                wd = _b16((Ci, 9 * Co), dev)
+                H.call('asr_conv_weight_pack16', H.ptr(conv.weight), H.ptr(wd), Co, Ci, 9 * Co, 1, st)
+                gin = _b16((Mp, Ci), dev)
+                H.call('asr_conv3x3_16', H.ptr(dpre), H.ptr(wd), H.ptr(gin), None, B, t_l, f_l, Co, Ci, 9 * Co, 1, H.ACT_NONE, 0, st)
+                g = gin
+        if mod.dp is not None:
+            mod.dp.bucket_ready(mod.bucket)
+        ctx.saved = None
+        return None, None, None, None
+
+
 class _VGGBase(nn.Module):
     def check_dim(self, input_dim):
         if input_dim % FBANK_SIZE != 0:
@@ -120,7 +249,8 @@ class _VGGBase(nn.Module):
         return input_dim // FBANK_SIZE, FBANK_SIZE, (FBANK_SIZE // 4) * self.hide_dim
 
     def forward(self, feature, feat_len, ctx=None):
-        out = _VGGFn.apply(ctx.anchor, feature, self, ctx.prec)
+        fn = _VGG16Fn if vgg16_ok(self, ctx.prec) else _VGGFn
+        out = fn.apply(ctx.anchor, feature, self, ctx.prec)
         return out, feat_len // 4
 
 

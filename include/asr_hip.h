@@ -358,6 +358,41 @@ int asr_specaug_ws(float* x, const int64_t* lens, const int* draws_in, int* draw
  */
 int asr_conv3x3(const float* img, const float* w_or_dout, float* out, const float* bias,
                 int B, int T, int F, int C, int N, int mode, int act, int accum, int prec, asr_stream_t stream);
+
+/* ---- bf16 VGG front-end (bf16 contraction mode), csrc/vgg16.hip ----------------------------------------------------
+ * The same layers - nn.Conv2d(k 3, stride 1, pad 1) + ReLU / CNNLayerNorm, nn.MaxPool2d(2, 2[, ceil_mode]) of
+ * /root/reference/src/module.py:599-614 (VGGExtractor_LN) and :670-681 (VGGExtractor) - on ZERO-BORDERED channel-last bf16
+ * images P(T,F,C) = (B, T+2, F+2, C): a tap of the 3x3 stencil is then a constant row shift of the pixel-row matrix and the
+ * convolution is an implicit GEMM on the direct-to-LDS bf16 contraction kernel (no bounds tests, no fp32 staging).
+ *   asr_vgg16_im2col      feature (B,T,Cin*F) fp32 -> patch matrix (B*(T+2)*(F+2), Kp) bf16 of the FIRST layer (Cin = 4: K = 36 -> Kp 40)
+ *   asr_conv_weight_pack16 (Co,Ci,3,3) fp32 -> (Co, Kp) bf16 [tap*Ci+ci] (mode 0) / flipped (Ci, Kp) [tap*Co+co] (mode 1: input gradient)
+ *   asr_conv3x3_16        out P(T,F,N) = act(conv(img) + bias), borders written as zeros; implicit = 1: img = P(T,F,C), C % 64 == 0,
+ *                         K = 9*C; implicit = 0: img = an explicit (rows, K) patch matrix over the same pixel grid
+ *   asr_conv3x3_16_wgrad  dw (N, ldw)[n][tap*C+ci] += sum_rows dout[row,n] img[row+shift(tap),ci]: nine shifted-row TN contractions in
+ *                         one launch (rows shifted outside the image read as zeros)
+ *   asr_conv_weight_fold  (Co,Ci,3,3) += (Co, ld)[tap*Ci+ci]
+ *   asr_maxpool2x2_16_*   on bordered images; idx: one byte per element of the bordered output
+ *                         out_f32 = 1: `out` is fp32 (no activation) - the pre-activations a CNNLayerNorm normalises next (rounded to bf16
+ *                         first, their rounding error would be amplified by mean / std)
+ *   asr_ln_freq16_*       CNNLayerNorm (LayerNorm over the F interior pixels, affine per f) + ReLU: x fp32 bordered in, y / dy / dx bf16
+ *                         bordered; stats (B*(T+2)*C, 2); dconv_bias (C, may be NULL) += per-channel sum of dx in fp32 = the gradient of
+ *                         the bias of the convolution in front (analytically zero)
+ *   asr_vgg16_output[_bwd] P(T,F,C) <-> (B, T, C*F) bf16, the encoder layout (channel-major), and its adjoint */
+int asr_vgg16_im2col(const float* feature, void* x1, int B, int T, int F, int Cin, int Kp, asr_stream_t stream);
+int asr_conv_weight_pack16(const float* src, void* dst, int Co, int Ci, int Kp, int mode, asr_stream_t stream);
+int asr_conv_weight_fold(const float* src, float* dst, int Co, int Ci, int ld, asr_stream_t stream);
+int asr_conv3x3_16(const void* img, const void* w, void* out, const float* bias, int B, int T, int F, int C, int N, int K, int implicit,
+                   int act, int out_f32, asr_stream_t stream);
+int asr_conv3x3_16_wgrad(const void* img, const void* dout, float* dw, int B, int T, int F, int C, int N, int ldw, int splits,
+                         asr_stream_t stream);
+int asr_maxpool2x2_16_fwd(const void* x, void* y, unsigned char* idx, int B, int T, int F, int C, int T2, int F2, asr_stream_t stream);
+int asr_maxpool2x2_16_bwd(const void* dy, const unsigned char* idx, void* dx, int B, int T, int F, int C, int T2, int F2, asr_stream_t stream);
+int asr_ln_freq16_fwd(const float* x, const float* w, const float* b, void* y, float* stats, int B, int T, int F, int C, float eps, int relu,
+                      asr_stream_t stream);
+int asr_ln_freq16_bwd(const void* dy, const float* x, const float* w, const float* b, const float* stats, void* dx, float* dw, float* db,
+                      float* dconv_bias, int B, int T, int F, int C, int relu, asr_stream_t stream);
+int asr_vgg16_output(const void* img, void* out, int B, int T, int F, int C, asr_stream_t stream);
+int asr_vgg16_output_bwd(const void* dout, void* g, int B, int T, int F, int C, asr_stream_t stream);
 int asr_conv_weight_permute(const float* src, float* dst, int Co, int Ci, int mode, asr_stream_t stream);
 int asr_maxpool2x2_fwd(const float* x, float* y, unsigned char* idx, int B, int T, int F, int C, int T2, int F2, asr_stream_t stream);
 int asr_maxpool2x2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int T, int F, int C, int T2, int F2,

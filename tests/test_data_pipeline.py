@@ -98,3 +98,49 @@ def test_solver_trains_from_waveform_shards(tmp_path):
     H.raise_if_aborted()
     assert s.step == 3
     assert any(f.startswith('best_') for f in os.listdir(s.ckpdir))
+
+
+def test_pcm_to_shards_reproduces_the_22050_hz_quirk(tmp_path):
+    """tools/pcm_to_shards.py: decoded PCM (RIFF/WAVE + LibriSpeech *.trans.txt) -> waveform shards the loader reads.  The
+    reference hands librosa.load's default 22 050 Hz samples to a front-end built for 16 kHz (src/audio.py:283-309): a
+    1 s / 16 kHz file becomes 22 050 samples (138 frames, not 100), a pure tone keeps its frequency in Hz at the stored rate."""
+    import importlib.util
+    import wave
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('pcm_to_shards', os.path.join(root, 'tools', 'pcm_to_shards.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    src = tmp_path / 'wav' / '19' / '198'
+    src.mkdir(parents=True)
+    sr = 16000
+    t = np.arange(sr) / sr
+    tones = {'19-198-0000': 440.0, '19-198-0001': 1000.0}
+    for uid, f0 in tones.items():
+        x = (0.5 * np.sin(2 * np.pi * f0 * t)).astype(np.float32)
+        with wave.open(str(src / (uid + '.wav')), 'wb') as w:
+            w.setnchannels(2); w.setsampwidth(2); w.setframerate(sr)
+            st = np.stack([x, x], axis=1)                                  # stereo: must be averaged to mono
+            w.writeframes((st * 32767).astype('<i2').tobytes())
+    (src / '19-198.trans.txt').write_text('19-198-0000 HELLO WORLD\n19-198-0001 SECOND LINE\n')
+    out = tmp_path / 'shards'
+    tool.main(['--src', str(tmp_path / 'wav'), '--out', str(out), '--split', 'train-clean-100'])
+    lines = (out / 'train-clean-100' / 'manifest.tsv').read_text().strip().split('\n')
+    assert len(lines) == 2
+    for line in lines:
+        uid, fn, n, text = line.split('\t')
+        assert int(n) == 22050 and text in ('HELLO WORLD', 'SECOND LINE')
+        y = np.load(out / 'train-clean-100' / fn)
+        assert y.dtype == np.float32 and len(y) == 22050 and abs(float(np.abs(y).max()) - 0.5) < 0.02
+        spec_ = np.abs(np.fft.rfft(y))
+        assert abs(float(np.argmax(spec_)) * 22050 / len(y) - tones[uid]) < 2.0          # same pitch in Hz at the stored rate
+    # and the nominal rate on request
+    tool.main(['--src', str(tmp_path / 'wav'), '--out', str(out), '--split', 'dev', '--sr', '16000', '--int16'])
+    y = np.load(out / 'dev' / '19-198-0000.npy')
+    assert y.dtype == np.int16 and len(y) == 16000
+    # the shard dataset reads what the tool wrote
+    from src.data import WaveformShardDataset
+    from src.text import load_text_encoder
+    tok = load_text_encoder('character', os.path.join(root, 'e2e-asr-pytorch_amd', 'corpus', 'librispeech_char.txt'))
+    ds = WaveformShardDataset(str(out), ['train-clean-100'], tok, bucket_size=1)
+    assert len(ds) == 2

@@ -1,5 +1,7 @@
 """Kernel-level parity of the VGG pieces (implicit-GEMM conv3x3 fwd / dgrad / wgrad, max-pool, LayerNorm over
 frequency, layout permutes) against torch on the CPU."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -97,3 +99,89 @@ def test_permute_last2():
     y = torch.empty(7, 5, 3, device='cuda')
     H.call('asr_permute_last2', H.ptr(x), H.ptr(y), 7, 3, 5, H.stream_ptr())
     assert torch.equal(y, x.transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize('kind,B,T', [('vgg1', 2, 52), ('vgg5', 3, 40), ('vgg1', 1, 7), ('vgg5', 2, 203)])
+def test_bf16_bordered_front_end_vs_torch(kind, B, T):
+    """The bf16 front-end on zero-bordered images (csrc/vgg16.hip: implicit-GEMM convolutions on the direct-to-LDS kernel, the
+    nine-tap weight gradient, bordered pooling / CNNLayerNorm) against the SAME layers in plain torch on the CPU (fp32):
+    output and every parameter / input gradient.  Odd T (trimmed to a multiple of 4), ceil- and floor-mode pooling.
+    Reference: src/module.py:582-716."""
+    import torch.nn as nn
+    from src import hipabi as H
+    from src.vgg import VGGExtractor, VGGExtractor_LN, _VGG16Fn, vgg16_ok
+    D = 160
+    torch.manual_seed(7 + T)
+    mod = (VGGExtractor if kind == 'vgg1' else VGGExtractor_LN)(D)
+    for p in mod.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.2, 0.2).add_(1.0 if p.numel() in (40, 20) else 0.0)       # LayerNorm gains near 1, biases small
+    ref = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.rand(B, T, D, generator=g)
+    dy_full = None
+
+    def torch_forward(xin):
+        Tt = xin.shape[1] - xin.shape[1] % 4
+        h = xin[:, :Tt].view(B, Tt, 4, 40).transpose(1, 2)                  # (B, C, T, F)
+        ext = mod.extractor
+        if kind == 'vgg1':
+            h = ext(h)
+        else:
+            for m in ext:
+                if isinstance(m, nn.Conv2d) or isinstance(m, (nn.ReLU, nn.MaxPool2d)):
+                    h = m(h)
+                else:                                                        # CNNLayerNorm: LayerNorm over F of (B, C, T, F)
+                    h = m.layer_norm(h)
+        h = h.transpose(1, 2)
+        return h.contiguous().view(B, h.shape[1], -1)
+
+    xr = x.clone().requires_grad_(True)
+    y_ref = torch_forward(xr)
+    dy = torch.randn(y_ref.shape, generator=g)
+    (y_ref * dy).sum().backward()
+    g_ref = {k: p.grad.detach().clone() for k, p in mod.named_parameters()}
+    for p in mod.parameters():
+        p.grad = None
+    modc = mod.cuda()
+    assert vgg16_ok(modc, H.BF16)
+    from src.vgg import _VGGFn
+    rep = {}
+    for name, fn in (('bordered bf16', _VGG16Fn), ('round-2 path (fp32 images, bf16 operands)', _VGGFn)):
+        for p in modc.parameters():
+            p.grad = torch.zeros_like(p)
+        anchor = torch.zeros(1, device='cuda', requires_grad=True)
+        y = fn.apply(anchor, x.cuda(), modc, H.BF16)
+        assert tuple(y.shape) == tuple(y_ref.shape)
+        err = (y.float().cpu() - y_ref.detach()).abs().max().item()
+        scale = y_ref.detach().abs().max().item()
+        assert err < 3e-2 * max(1.0, scale), (name, err, scale)
+        y.backward(dy.cuda().to(y.dtype))
+        torch.cuda.synchronize()
+        gmax = max(float(v.norm()) for v in g_ref.values())
+        rows = []
+        for k, p in modc.named_parameters():
+            a, r = p.grad.double().cpu().reshape(-1), g_ref[k].double().reshape(-1)
+            if float(r.norm()) < 1e-4 * gmax:
+                # analytically zero (the bias of a convolution in front of a CNNLayerNorm): both sides are rounding noise
+                rows.append((k, None, float(a.norm()) / gmax))
+                continue
+            cos = float((a * r).sum() / (a.norm() * r.norm() + 1e-30))
+            rows.append((k, round(cos, 5), round(float(a.norm() / (r.norm() + 1e-30)), 4)))
+        rep[name] = rows
+    # The bound: the SURVEY 8d tolerance for bf16 compute (cosine >= 0.99) wherever the round-2 path (fp32 images, operands rounded
+    # to bf16 when staged - the same number of roundings per contraction) meets it itself, and never worse than that path by more
+    # than 0.004: a dense random output gradient through four bf16 contractions leaves the FIRST layer's weight gradient (36
+    # inputs, a sum over every pixel) near 0.987 on either path.
+    new_rows, old_rows = rep['bordered bf16'], rep['round-2 path (fp32 images, bf16 operands)']
+    bad = []
+    for rn, ro in zip(new_rows, old_rows):
+        if rn[1] is None:
+            if rn[2] > 1e-3:
+                bad.append((rn, ro))
+        elif rn[1] < min(0.99, ro[1] - 0.004) or rn[1] < 0.98 or abs(rn[2] - 1) > 4e-2:
+            bad.append((rn, ro))
+    if os.environ.get('ASR_DUMP_DIR'):
+        import json
+        json.dump(rep, open(os.path.join(os.environ['ASR_DUMP_DIR'], 'vgg16_%s_%d_%d.json' % (kind, B, T)), 'w'), indent=1)
+    assert y_ref is not None and not bad, bad

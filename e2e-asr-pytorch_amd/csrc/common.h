@@ -34,6 +34,18 @@ void asr_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// true the first time it is called for the CURRENT device with this flag array: kernel attributes (dynamic-LDS limits) are
+// per device, so the "already set" marks are too (a process-wide bool would leave the second GPU of a process unset).  The
+// marks are write-once and the guarded calls idempotent: two threads racing here set the attribute twice, nothing else.
+static inline bool first_on_device(unsigned char (&done)[32]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    dev &= 31;
+    if (done[dev]) return false;
+    done[dev] = 1;
+    return true;
+}
+
 // ---- device math --------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 

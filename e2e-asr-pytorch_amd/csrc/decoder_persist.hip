@@ -620,7 +620,8 @@ int dec_fwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
     const dim3 grid(8 * cpx * pl.NT), block(64 * (NCW + NPW));
 #define DPF_LAUNCH(KN_, TPW_)                                                                                                   \
     {                                                                                                                           \
-        hipFuncSetAttribute((const void*)dec_fwd_persist<KN_, TPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); /* per device, every call: no process-wide flag */ \
+        static unsigned char attr_[32];                                                                                         \
+        if (first_on_device(attr_)) hipFuncSetAttribute((const void*)dec_fwd_persist<KN_, TPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); \
         if (!grid_resident(dec_fwd_persist<KN_, TPW_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                              \
         hipLaunchKernelGGL((dec_fwd_persist<KN_, TPW_>), grid, block, pl.lds, st, p);                                             \
         hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                   \
@@ -1203,7 +1204,8 @@ int dec_bwd_persistent(const asr_dec_dims_t& d, const asr_dec_weights_t& w, cons
     const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
 #define DPB_LAUNCH(KN_, TE_)                                                                                                    \
     {                                                                                                                           \
-        hipFuncSetAttribute((const void*)dec_bwd_persist<KN_, TE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
+        static unsigned char attr_[32];                                                                                         \
+        if (first_on_device(attr_)) hipFuncSetAttribute((const void*)dec_bwd_persist<KN_, TE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
         if (!grid_resident(dec_bwd_persist<KN_, TE_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                               \
         hipLaunchKernelGGL((dec_bwd_persist<KN_, TE_>), grid, block, pl.lds, st, p);                                              \
         hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                   \

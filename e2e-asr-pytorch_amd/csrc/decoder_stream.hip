@@ -601,7 +601,8 @@ int dec_fwd_streamed(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const 
     const dim3 grid(8 * cpx * pl.NT), block(64 * (NCW + NPW));
 #define DSF_LAUNCH(KN_)                                                                                                         \
     {                                                                                                                           \
-        hipFuncSetAttribute((const void*)dec_fwd_stream<KN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);   \
+        static unsigned char attr_[32];                                                                                         \
+        if (first_on_device(attr_)) hipFuncSetAttribute((const void*)dec_fwd_stream<KN_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); \
         if (!grid_resident(dec_fwd_stream<KN_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                                   \
         hipLaunchKernelGGL((dec_fwd_stream<KN_>), grid, block, pl.lds, st, p);                                                  \
         hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                 \
@@ -1421,7 +1422,8 @@ int dec_bwd_streamed(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const 
     const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
 #define DSB_LAUNCH(KN_, RES_)                                                                                                   \
     {                                                                                                                           \
-        hipFuncSetAttribute((const void*)dec_bwd_stream<KN_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
+        static unsigned char attr_[32];                                                                                         \
+        if (first_on_device(attr_)) hipFuncSetAttribute((const void*)dec_bwd_stream<KN_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
         if (!grid_resident(dec_bwd_stream<KN_, RES_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                             \
         hipLaunchKernelGGL((dec_bwd_stream<KN_, RES_>), grid, block, pl.lds, st, p);                                            \
         hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                 \

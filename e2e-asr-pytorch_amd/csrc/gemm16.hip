@@ -291,7 +291,8 @@ struct T16P {
 
 __device__ __forceinline__ int swz_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-__global__ __launch_bounds__(NTH, 3) void gemm16_tn_kernel(T16P p) {
+template <int STAGES>
+__global__ __launch_bounds__(NTH, STAGES == 1 ? 3 : 2) void gemm16_tn_kernel(T16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // A tile [64][256 B] | B tile [64][256 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,11 +360,7 @@ __global__ __launch_bounds__(NTH, 3) void gemm16_tn_kernel(T16P p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(base + BK * 256 + (4 * w + i) * 1024), 16, vb, 0, 0, 0);
         }
     };
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = 0;
-        stage(kt, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    auto compute = [&](int buf) {
         const unsigned char* As = smem + buf * STAGE_BYTES;
         const unsigned char* Bs = As + BK * 256;
 #pragma unroll
@@ -387,8 +384,33 @@ __global__ __launch_bounds__(NTH, 3) void gemm16_tn_kernel(T16P p) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = mma16(af[a], bf[b], acc[a][b]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    };
+    if constexpr (STAGES == 1) {
+        for (int kt = kt0; kt < kt1; ++kt) {
+            stage(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // two LDS stages (long reduction slices: few splits, little split-K traffic): the loads of k-step kt+1 are in flight
+        // across a raw barrier with a counted wait, as in gemm16_nt_kernel
+        stage(kt0, 0);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) {
+                stage(kt + 1, buf ^ 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            compute(buf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 
     // epilogue: acc[a][b][r] = C[i = i0 + wr*64 + 16a + 4*fq + r][j = j0 + wc*64 + 16b + fr]
@@ -430,7 +452,15 @@ int gemm16_tn_taps(const void* A, const void* B, float* C, int I, int J, int R, 
            cdiv(I, BM), cdiv(J, BN), splits, cdiv(nk, splits), seqT, bshift, perm_h, seqT > 0 ? 1.0f / (float)seqT : 0.f, tapF2};
     const long total = (long)p.nti * p.ntj * p.splits * (tapF2 > 0 ? 9 : 1);
     if (total >= (1L << 31)) return 1;
-    hipLaunchKernelGGL(gemm16_tn_kernel, dim3((unsigned)total), dim3(NTH), STAGE_BYTES, st, p);
+    // ASR_GEMM16_TN_STAGES=2: the double-buffered instantiation (two workgroups per CU); default one stage, three per CU
+    static const int stages = [] { const char* e = getenv("ASR_GEMM16_TN_STAGES"); return (e && e[0] == '2') ? 2 : 1; }();
+    if (stages == 2) {
+        static const bool once = [] { hipFuncSetAttribute((const void*)gemm16_tn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); return true; }();
+        (void)once;
+        hipLaunchKernelGGL(gemm16_tn_kernel<2>, dim3((unsigned)total), dim3(NTH), 2 * STAGE_BYTES, st, p);
+    } else {
+        hipLaunchKernelGGL(gemm16_tn_kernel<1>, dim3((unsigned)total), dim3(NTH), STAGE_BYTES, st, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { asr_set_error("asr_gemm16(tn): launch failed: %s", hipGetErrorString(e)); return ASR_E_LAUNCH; }
     return ASR_OK;

@@ -138,7 +138,7 @@ def test_bf16_bordered_front_end_vs_torch(kind, B, T):
 
     xr = x.clone().requires_grad_(True)
     y_ref = torch_forward(xr)
-    dy = torch.randn(y_ref.shape, generator=g)
+    dy = torch.randn(y_ref.shape, generator=g).to(torch.bfloat16).float()      # what the bf16 recurrent layer behind hands back
     (y_ref * dy).sum().backward()
     g_ref = {k: p.grad.detach().clone() for k, p in mod.named_parameters()}
     for p in mod.parameters():
@@ -171,7 +171,7 @@ def test_bf16_bordered_front_end_vs_torch(kind, B, T):
         rep[name] = rows
     # The bound: the SURVEY 8d tolerance for bf16 compute (cosine >= 0.99) wherever the round-2 path (fp32 images, operands rounded
     # to bf16 when staged - the same number of roundings per contraction) meets it itself, and never worse than that path by more
-    # than 0.004: a dense random output gradient through four bf16 contractions leaves the FIRST layer's weight gradient (36
+    # than 0.008 (norm ratio: within 2e-2 of that path's): a dense random output gradient through four bf16 contractions leaves the FIRST layer's weight gradient (36
     # inputs, a sum over every pixel) near 0.987 on either path.
     new_rows, old_rows = rep['bordered bf16'], rep['round-2 path (fp32 images, bf16 operands)']
     bad = []
@@ -179,7 +179,7 @@ def test_bf16_bordered_front_end_vs_torch(kind, B, T):
         if rn[1] is None:
             if rn[2] > 1e-3:
                 bad.append((rn, ro))
-        elif rn[1] < min(0.99, ro[1] - 0.004) or rn[1] < 0.98 or abs(rn[2] - 1) > 4e-2:
+        elif rn[1] < min(0.99, ro[1] - 0.008) or rn[1] < 0.98 or abs(rn[2] - 1) > max(4e-2, abs(ro[2] - 1) + 2e-2):
             bad.append((rn, ro))
     if os.environ.get('ASR_DUMP_DIR'):
         import json

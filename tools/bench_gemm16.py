@@ -15,6 +15,8 @@ SHAPES = [  # (name, form, M, N, K)
     ('L0/L1 dW_hh (one direction)', 'tn', 1280, 320, 19200), ('L0 dW_pj', 'tn', 640, 640, 19200), ('L1-L3 dW_pj', 'tn', 640, 640, 9600),
 ]
 res = []
+if '--tn-only' in sys.argv:
+    SHAPES = [x for x in SHAPES if x[1] == 'tn']
 for name, form, M, N, K in SHAPES:
     g = torch.Generator().manual_seed(1)
     if form == 'nt':
@@ -24,6 +26,8 @@ for name, form, M, N, K in SHAPES:
     else:
         A = torch.randn(K, M, generator=g).to(torch.bfloat16).cuda(); B = torch.randn(K, N, generator=g).to(torch.bfloat16).cuda()
         C = torch.zeros(M, N, device='cuda'); sp = H.wgrad_splits(K, M, N)
+        if os.environ.get('ASR_TN_SPLITS'):
+            sp = int(os.environ['ASR_TN_SPLITS'])
         run = lambda: H.gemm16(A, B, C, M, N, K, M, N, N, 0, 0, accum=1, splits=sp)
     for _ in range(3):
         run()
@@ -35,7 +39,7 @@ for name, form, M, N, K in SHAPES:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
     tf = 2.0 * M * N * K / us / 1e6
-    res.append({'name': name, 'form': form, 'M': M, 'N': N, 'K': K, 'us': us, 'tflops': tf, 'frac_of_2500': tf / 2500.0})
+    res.append({'name': name, 'form': form, 'M': M, 'N': N, 'K': K, 'splits': (sp if form == 'tn' else None), 'us': us, 'tflops': tf, 'frac_of_2500': tf / 2500.0})
     print('%-32s %s  M=%6d N=%5d K=%6d  %8.1f us  %7.1f TFLOP/s  (%.3f of the bf16 peak)' % (name, form, M, N, K, us, tf, tf / 2500.0))
 if '--json' in sys.argv:
     json.dump(res, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)

@@ -26,6 +26,10 @@ python3 bench.py --vgg 1 --tokens 100 --steps 10 --warmup 3 --no-cpu-baseline > 
 python3 bench.py --vgg 5 --tokens 100 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_vgg5.json 2> $OUT/bench_vgg5.err && echo "vgg5 done"
 python3 bench.py --waveform --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_waveform.json 2> $OUT/bench_waveform.err && echo "waveform done"
 python3 bench.py --batch 64 --frames 3000 --tokens 400 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_config5.json 2> $OUT/bench_config5.err && echo "config5 done"
+python3 bench.py --shape librispeech --steps 16 --warmup 8 --no-cpu-baseline > $OUT/bench_librispeech_shape.json 2> $OUT/bench_librispeech_shape.err && echo "librispeech-shaped buckets done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof5 -o x -- python3 bench.py --batch 64 --frames 3000 --tokens 400 --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/prof5.err \
+  || { echo "rocprofv3 config-5 pass exited $?"; tail -5 $OUT/prof5.err; exit 1; }
+cp $(find $OUT/prof5 -name "x_kernel_stats.csv" | head -1) $OUT/bench_config5_kernel_stats.csv && rm -rf $OUT/prof5 && echo "config5 kernel stats done"
 python3 tools/bench_decode.py > $OUT/decode_config4.json 2> $OUT/decode_config4.err && echo "decode done"
 python3 tools/bench_decode.py --utts 1 > $OUT/decode_config4_single.json 2>> $OUT/decode_config4.err
 ls -la $OUT

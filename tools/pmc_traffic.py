@@ -19,7 +19,7 @@ def per_kernel(path, counter):
         if r['Counter_Name'] != counter:
             continue
         name = r['Kernel_Name']
-        for key in ('lstm_fwd_p3', 'lstm_bwd_p3', 'lstm_fwd_p2', 'lstm_bwd_p2', 'dec_fwd_persist', 'dec_bwd_persist', 'att_bwd_energy_kernel',
+        for key in ('lstm_fwd_p3', 'lstm_bwd_p3', 'lstm_fwd_p2', 'lstm_bwd_p2', 'dec_fwd_persist', 'dec_bwd_persist', 'dec_fwd_stream', 'dec_bwd_stream', 'att_bwd_energy_kernel',
                     'att_energy_kernel', 'gemm16_nt_kernel', 'gemm16_tn_kernel', 'gemm_kernel'):
             if key in name:
                 a = acc.setdefault(key, [0, 0.0])

@@ -292,7 +292,7 @@ struct T16P {
 __device__ __forceinline__ int swz_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
 template <int STAGES>
-__global__ __launch_bounds__(NTH, STAGES == 1 ? 3 : 2) void gemm16_tn_kernel(T16P p) {
+__global__ __launch_bounds__(NTH, STAGES == 1 ? 3 : (STAGES == 2 ? 2 : 1)) void gemm16_tn_kernel(T16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // A tile [64][256 B] | B tile [64][256 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -395,19 +395,23 @@ __global__ __launch_bounds__(NTH, STAGES == 1 ? 3 : 2) void gemm16_tn_kernel(T16
             __builtin_amdgcn_s_barrier();
         }
     } else {
-        // two LDS stages (long reduction slices: few splits, little split-K traffic): the loads of k-step kt+1 are in flight
-        // across a raw barrier with a counted wait, as in gemm16_nt_kernel
-        stage(kt0, 0);
+        // STAGES LDS stages, STAGES - 1 k-steps of direct-to-LDS loads in flight (one workgroup per CU at 4 stages): a
+        // single workgroup's k-step is otherwise one exposed L2 round trip (~1 us) per 0.2 us of MFMA work - measured
+        // 1.4 us per k-step at one workgroup per CU - and many short split-K slices pay for that hiding with fp32 atomics
+        // (900 workgroups x 64 KB on the 2560 x 640 gradient).  Counted waits: 8 loads per stage and wave.
+        constexpr int AHEAD = STAGES - 1;
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) if (kt0 + i < kt1) stage(kt0 + i, i);
         for (int kt = kt0; kt < kt1; ++kt) {
-            const int buf = (kt - kt0) & 1;
-            if (kt + 1 < kt1) {
-                stage(kt + 1, buf ^ 1);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            const int rel = kt - kt0;
+            if (kt + AHEAD < kt1) stage(kt + AHEAD, (rel + AHEAD) % STAGES);
+            const int inflight = min(AHEAD, kt1 - 1 - kt);          // k-steps requested behind this one
+            if (inflight >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (inflight == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (inflight == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            compute(buf);
+            compute(rel % STAGES);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -453,8 +457,12 @@ int gemm16_tn_taps(const void* A, const void* B, float* C, int I, int J, int R, 
     const long total = (long)p.nti * p.ntj * p.splits * (tapF2 > 0 ? 9 : 1);
     if (total >= (1L << 31)) return 1;
     // ASR_GEMM16_TN_STAGES=2: the double-buffered instantiation (two workgroups per CU); default one stage, three per CU
-    static const int stages = [] { const char* e = getenv("ASR_GEMM16_TN_STAGES"); return (e && e[0] == '2') ? 2 : 1; }();
-    if (stages == 2) {
+    static const int stages = [] { const char* e = getenv("ASR_GEMM16_TN_STAGES"); return e ? atoi(e) : 1; }();
+    if (stages == 4) {
+        static unsigned char attr4_[32];
+        if (first_on_device(attr4_)) hipFuncSetAttribute((const void*)gemm16_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES);
+        hipLaunchKernelGGL(gemm16_tn_kernel<4>, dim3((unsigned)total), dim3(NTH), 4 * STAGE_BYTES, st, p);
+    } else if (stages == 2) {
         static const bool once = [] { hipFuncSetAttribute((const void*)gemm16_tn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); return true; }();
         (void)once;
         hipLaunchKernelGGL(gemm16_tn_kernel<2>, dim3((unsigned)total), dim3(NTH), 2 * STAGE_BYTES, st, p);

@@ -52,8 +52,8 @@ __device__ __forceinline__ void dp_jitter(unsigned k, unsigned step, unsigned ep
     }
 }
 #define DP_DECL
-#define DP_MARK(k) dp_jitter(k, (unsigned)t, p.epoch);
-#define DP_JIT(k) dp_jitter(32 + k, (unsigned)t, p.epoch);
+#define DP_MARK(k) dp_jitter(k, (unsigned)t, epoch_);
+#define DP_JIT(k) dp_jitter(32 + k, (unsigned)t, epoch_);
 #define DP_DUMP
 #else
 #define DP_DECL
@@ -114,6 +114,94 @@ struct PD {
     int allow_local;
     unsigned epoch;                 // launch counter (tag bits)
 };
+
+// ---- location convolution on the matrix cores -----------------------------------------------------------------------------------
+// conv[k][tau] = sum_jj W_conv[k][jj] * att[tau + jj - Ks] (reference src/module.py:1161-1189, Conv1d(1, Kn, 2 Ks + 1, padding Ks)) is a
+// Toeplitz product: for a 16-frame tile, A[m][jj] = P[16 mt + m + jj] (P = the zero-padded attention row from the tile's first frame
+// on) times B[jj][k] = W_conv[k][jj].  The A fragment of lane (m, q) is 8 CONSECUTIVE elements of P starting at an offset whose low
+// two bits are m & 3, so the bf16 image of P is kept in four copies shifted by 0..3 elements: every fragment is then two aligned
+// 8-byte LDS reads.  Precision: both operands are split hi + lo (bf16 + bf16 of the remainder) and three products are kept
+// (hi hi, hi lo, lo hi): ~2^-16 relative, the fp32 VALU loop it replaces needed 16 FMAs per three 16-byte LDS reads and was bound
+// by the LDS port and the FMA rate (16.7 us per step on the 384-frame tiles of config 5, tools/diag_dec_stream.py).
+struct ConvGeo { int NKS, WKP, IMG_LD, need; };
+__host__ __device__ inline ConvGeo conv_geo(int TEB, int Ks) {
+    ConvGeo g;
+    g.NKS = (2 * Ks + 1 + 31) >> 5;                       // 32-tap steps of the contraction
+    g.WKP = 32 * g.NKS + 8;                               // row of the filter image: 2 WKP bytes = an odd multiple of 16 modulo 256
+    g.need = ((TEB + 15) & ~15) + 32 * g.NKS + 8;         // window elements a tile can touch
+    g.IMG_LD = ((g.need - 32 + 127) / 128) * 128 + 32;    // 2 IMG_LD = 64 modulo 256: the four copies sit in disjoint banks
+    return g;
+}
+__host__ __device__ inline int conv_img_shorts(const ConvGeo& g) { return 8 * g.IMG_LD + 32 * g.WKP; }     // {hi, lo} x 4 copies | {hi, lo} x 16 rows
+
+// filter image: rows n < Kn hold W_conv[n][0 .. taps) split hi | lo, everything else zero (once per launch)
+__device__ inline void conv_build_wimg(const float* __restrict__ Wconv, int Kn, int taps, const ConvGeo& g, unsigned short* wimg, int tid, int nthr) {
+    for (int i = tid; i < 16 * g.WKP; i += nthr) {
+        const int n = i / g.WKP, x = i - n * g.WKP;
+        const float v = (n < Kn && x < taps) ? Wconv[n * taps + x] : 0.f;
+        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+        wimg[i] = __builtin_bit_cast(unsigned short, hi);
+        wimg[16 * g.WKP + i] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+
+// window image of the step: src[i] for 0 <= i < navail (zero beyond), copy c holds element i at position i - c
+__device__ inline void conv_build_ximg(const float* src, int navail, const ConvGeo& g, unsigned short* ximg, int tz, int nthr) {
+    const int ngrp = g.IMG_LD >> 2;
+    for (int it = tz; it < 4 * ngrp; it += nthr) {
+        const int c = it / ngrp, gq = it - c * ngrp;
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * gq + c + e;
+            const float v = (i < navail && i < g.need) ? src[i] : 0.f;
+            const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+            h[e] = __builtin_bit_cast(unsigned short, hi); l[e] = __builtin_bit_cast(unsigned short, lo);
+        }
+        *reinterpret_cast<uint2*>(ximg + (long)c * g.IMG_LD + 4 * gq) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2*>(ximg + (long)(4 + c) * g.IMG_LD + 4 * gq) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    }
+}
+
+// conv[k][16 mt + n] for the MTB 16-frame tiles of the window, tiles dealt to the NW waves three at a time.  The filter is the
+// row operand, so lane (n = lane & 15, q = lane >> 4) ends up with kernels 4 q .. 4 q + 3 of frame 16 mt + n: epi(mt, n, q, acc)
+template <int NW, class Epi>
+__device__ inline void conv_mfma(const unsigned short* ximg, const unsigned short* wimg, const ConvGeo& g, int MTB, int wave, int lane, Epi epi) {
+    constexpr int CT = 3;
+    const int m = lane & 15, q = lane >> 4, cc = m & 3;
+    const unsigned short* xh = ximg + (long)cc * g.IMG_LD + (m - cc) + 8 * q;
+    const unsigned short* xl = xh + 4 * g.IMG_LD;
+    const unsigned short* wh = wimg + m * g.WKP + 8 * q;
+    const unsigned short* wl = wh + 16 * g.WKP;
+    for (int mt0 = wave; mt0 < MTB; mt0 += NW * CT) {
+        f32x4 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < g.NKS; ++ks) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + 32 * ks), bl = *reinterpret_cast<const bf16x8*>(wl + 32 * ks);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int mt = mt0 + NW * c;
+                if (mt < MTB) {
+                    const unsigned short* ph = xh + 16 * mt + 32 * ks;
+                    const unsigned short* pl = xl + 16 * mt + 32 * ks;
+                    const uint2 h0 = *reinterpret_cast<const uint2*>(ph), h1 = *reinterpret_cast<const uint2*>(ph + 4);
+                    const uint2 l0 = *reinterpret_cast<const uint2*>(pl), l1 = *reinterpret_cast<const uint2*>(pl + 4);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                    acc[c] = mma16(bh, ah, acc[c]);
+                    acc[c] = mma16(bl, ah, acc[c]);
+                    acc[c] = mma16(bh, al, acc[c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int mt = mt0 + NW * c;
+            if (mt < MTB) epi(mt, m, q, acc[c]);
+        }
+    }
+}
 
 // barrier among the NCW compute waves only (the polling waves are inside a spin loop at these points)
 __device__ __forceinline__ void compute_barrier(unsigned* cnt, unsigned& gen) {

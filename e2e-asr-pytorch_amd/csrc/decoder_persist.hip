@@ -70,14 +70,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
     unsigned short* s_key = reinterpret_cast<unsigned short*>(smem);                 // [TE/4][A][4] bf16 (four frames innermost)
     unsigned short* s_enc = s_key + ((TE * A + 7) & ~7);                              // [TE][E] bf16
     unsigned short* s_cvx = s_enc + ((TE * E + 7) & ~7);                              // [16*MT][32] bf16 conv tile of the step, slots {hi | lo | hi}
-    float* s_x2 = reinterpret_cast<float*>(s_cvx + EPL * FCVX_LD);                    // [2][KCP]  ctx_t | h_{t-1} | 0, by step parity
+    const ConvGeo cg_ = conv_geo(EPL, Ks);
+    unsigned short* s_ximg = s_cvx + EPL * FCVX_LD;                                   // window image of the attention row, {hi, lo} x 4 shifts
+    unsigned short* s_wimg = s_ximg + 8 * cg_.IMG_LD;                                 // filter image {hi, lo} x 16 rows (decoder_cluster.h::conv_mfma)
+    float* s_x2 = reinterpret_cast<float*>(s_wimg + 32 * cg_.WKP);                    // [2][KCP]  ctx_t | h_{t-1} | 0, by step parity
     float* s_q = s_x2 + 2 * p.KCP;                                                       // [A]
     float* s_wg = s_q + ((A + 3) & ~3);                                               // [A]
     const int WT = (taps + 3) & ~3;                                                    // zero-padded filter row (16-byte units)
     const int ATP = (NT * TE + 2 * Ks + 8 + 3) & ~3;
     float* s_attp = s_wg + ((A + 3) & ~3);                                             // [Ks + NT*TE + Ks + 8]  zero-padded previous attention
-    float* s_wc = s_attp + ATP;                                                       // [Kn][WT]
-    float* s_epart = s_wc + Kn * WT;                                                  // [NCW][16*MT] energy partials of the compute waves
+    float* s_epart = s_attp + ATP;                                                    // [NCW][16*MT] energy partials of the compute waves
     float* s_g = s_epart + NCW * EPL;                                                 // [4*UPW]
     float* s_stage = s_g + ((4 * p.UPW + 3) & ~3);                                    // [NT][2*SG2]
     if (tid == 0) s_bar = 0u;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
         s_enc[i] = f2bf_bits(p.enc[((long)b * Tp + min(tau0 + f, tmax)) * E + c]);
     }
     for (int i = tid; i < EPL * FCVX_LD; i += blockDim.x) s_cvx[i] = 0;
-    for (int i = tid; i < Kn * WT; i += blockDim.x) { const int k = i / WT, jj = i - k * WT; s_wc[i] = (jj < taps) ? p.w.Wconv[k * taps + jj] : 0.f; }
+    conv_build_wimg(p.w.Wconv, Kn, taps, cg_, s_wimg, tid, blockDim.x);
     for (int i = tid; i < A; i += blockDim.x) s_wg[i] = p.w.wg[i];
     for (int i = tid; i < 2 * p.KCP; i += blockDim.x) s_x2[i] = 0.f;
     {
@@ -306,44 +308,34 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
         }
         DP_MARK(2)
-        // ---- location convolution of the tile from the previous attention row (runs while the query is gathered):
-        //      item = (tap range, kernel, group of 4 frames) with a sliding register window, partial sums meet in LDS
+        // ---- location convolution of the tile from the previous attention row (runs while the query is gathered): a Toeplitz
+        //      product on the matrix cores (decoder_cluster.h::conv_mfma).  A lane ends up with four kernels of one frame: the
+        //      {hi | lo | hi} slots of the sweep's operand row (the A operand of its MFMA) are written straight from the accumulator
         {
-            constexpr int ngrp = TE / 4;
-            const int nout = Kn * ngrp;
-            const int parts = max(1, min(8, (64 * NCW) / nout));
-            const int gpp = (WT / 4 + parts - 1) / parts;                // four-tap groups per part
-            float* s_part = s_stage;                                     // free until the S gather of this step
-            for (int it = tz; it < parts * nout; it += 64 * NCW) {
-                const int pz = it / nout, o = it - pz * nout, k = o / ngrp, ig = o - k * ngrp;
-                const int g0 = pz * gpp, g1 = min(WT / 4, g0 + gpp);
-                // 16-byte units: pa4[g] = prev_att[tau0 + 4ig + 4g - Ks ..+3]; out[i] = sum_jj w[jj] * pa[i + jj]
-                const float4* wk4 = reinterpret_cast<const float4*>(s_wc) + (k * WT) / 4;
-                const float4* pa4 = reinterpret_cast<const float4*>(s_attp) + tau0 / 4 + ig;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 3
-                for (int g = g0; g < g1; ++g) {
-                    const float4 w4 = wk4[g], lo = pa4[g], hi = pa4[g + 1];
-                    a0 += w4.x * lo.x + w4.y * lo.y + w4.z * lo.z + w4.w * lo.w;
-                    a1 += w4.x * lo.y + w4.y * lo.z + w4.z * lo.w + w4.w * hi.x;
-                    a2 += w4.x * lo.z + w4.y * lo.w + w4.z * hi.x + w4.w * hi.y;
-                    a3 += w4.x * lo.w + w4.y * hi.x + w4.z * hi.y + w4.w * hi.z;
-                }
-                *reinterpret_cast<float4*>(s_part + (long)pz * Kn * TE + k * TE + 4 * ig) = make_float4(a0, a1, a2, a3);
-            }
+            conv_build_ximg(s_attp + tau0, ATP - tau0, cg_, s_ximg, tz, 64 * NCW);
             compute_barrier(&s_bar, gen);
-            for (int o = tz; o < Kn * TE; o += 64 * NCW) {
-                float v = 0.f;
-                for (int pz = 0; pz < parts; ++pz) v += s_part[(long)pz * Kn * TE + o];
-                const int k = o / TE, i = o - k * TE;
-                {   // split-bf16 image of the conv tile: the A operand of the sweep's MFMA (slots hi | lo | hi)
-                    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-                    unsigned short* r = s_cvx + i * FCVX_LD;
-                    r[k] = __builtin_bit_cast(unsigned short, hi); r[KNMAX + k] = __builtin_bit_cast(unsigned short, lo);
-                    r[2 * KNMAX + k] = __builtin_bit_cast(unsigned short, hi);
+            conv_mfma<NCW>(s_ximg, s_wimg, cg_, MT, wave, lane, [&](int mt, int n, int q4, const f32x4& acc) {
+                const int i = 16 * mt + n;
+                unsigned short* r = s_cvx + i * FCVX_LD;
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int k0 = 4 * q4 + 2 * pp;
+                    if (k0 < Kn && i < TE) {
+                        const float v0 = acc[2 * pp], v1 = acc[2 * pp + 1];
+                        const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+                        const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+                        const unsigned hh = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                        const unsigned ll = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                        *reinterpret_cast<unsigned*>(r + k0) = hh;
+                        *reinterpret_cast<unsigned*>(r + KNMAX + k0) = ll;
+                        *reinterpret_cast<unsigned*>(r + 2 * KNMAX + k0) = hh;
+                        if (p.s.conv && tau0 + i < Tp) {
+                            p.s.conv[(row * Kn + k0) * Tp + tau0 + i] = v0;
+                            if (k0 + 1 < Kn) p.s.conv[(row * Kn + k0 + 1) * Tp + tau0 + i] = v1;
+                        }
+                    }
                 }
-                if (p.s.conv && tau0 + i < Tp) p.s.conv[(row * Kn + k) * Tp + tau0 + i] = v;
-            }
+            });
         }
         DP_MARK(3)
         __syncthreads();                                                // B2: s_q holds q_t, s_cvx the tile's conv
@@ -566,10 +558,9 @@ PersistPlan persist_plan(const asr_dec_dims_t& d) {
     const int taps = 2 * d.Ks + 1;
     size_t fl = 0;
     const int epl = 16 * cdiv(pl.TE, 16);
-    fl += 2 * pl.KCP + 2 * ((d.A + 3) & ~3) + ((pl.NT * pl.TE + 2 * d.Ks + 8 + 3) & ~3) + (size_t)d.Kn * ((taps + 3) & ~3) +
-          (size_t)NCW * epl + ((4 * pl.UPW + 3) & ~3) +
-          std::max((size_t)pl.NT * 2 * pl.SG2, (size_t)8 * d.Kn * pl.TE);      // the record stage doubles as the conv's partial-sum area
-    pl.lds = 2 * (size_t)(((pl.TE * d.A + 7) & ~7) + ((pl.TE * d.E + 7) & ~7) + epl * FCVX_LD) + 4 * fl;
+    fl += 2 * pl.KCP + 2 * ((d.A + 3) & ~3) + ((pl.NT * pl.TE + 2 * d.Ks + 8 + 3) & ~3) +
+          (size_t)NCW * epl + ((4 * pl.UPW + 3) & ~3) + (size_t)pl.NT * 2 * pl.SG2;
+    pl.lds = 2 * (size_t)(((pl.TE * d.A + 7) & ~7) + ((pl.TE * d.E + 7) & ~7) + epl * FCVX_LD + conv_img_shorts(conv_geo(epl, d.Ks))) + 4 * fl;
     if (pl.lds > 156 * 1024) return pl;
     pl.status_bytes = 4096;
     pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.HG2 + pl.QG2 + pl.SG2) * sizeof(u64));

@@ -26,7 +26,7 @@ struct PSF {
     const int64_t* enc_len;
     const unsigned short* wcat16;   // (4Dd, KCP) bf16 rows [W_ih[:, Dd:Dd+E] | W_hh | 0-pad]
     const float* embproj;           // (B*L, 4Dd)  W_ih[:, :Dd] . emb(token)
-    const unsigned short* key16t;   // [B][NT*TEB/4][A][4] bf16: four frames innermost (the sweep's fragment), frames >= T' clamped
+    const unsigned short* key16t;   // [B][NT][pair][q][A][2][4] bf16: a lane's fragments of two 16-frame tiles side by side (build_key16p_kernel)
     u64* xbuf;
     unsigned* status;
     int NT, TEB, UPW, QPW, CPW;
@@ -36,10 +36,12 @@ struct PSF {
 };
 
 // LDS carve (floats behind the bf16 conv tile), shared by kernel and host plan
-struct FCarve { int cvx_shorts, WT, ATP, NG, x2, q, wg, attp, wc, epart, e, w, g, cpart, stage, stage_floats, floats; };
+struct FCarve { int cvx_shorts, img, shorts, WT, ATP, NG, x2, q, wg, attp, wc, epart, e, w, g, cpart, stage, stage_floats, floats; };
 __host__ __device__ inline FCarve fwd_carve(int TEB, int NT, int A, int E, int Kn, int Ks, int KCP, int UPW, int SG2) {
     FCarve c;
     c.cvx_shorts = TEB * FCVX_LD;
+    c.img = (c.cvx_shorts + 7) & ~7;                          // bf16 images of the convolution (conv_geo)
+    c.shorts = (c.img + conv_img_shorts(conv_geo(TEB, Ks)) + 7) & ~7;
     c.WT = (2 * Ks + 1 + 3) & ~3;
     c.ATP = (NT * TEB + 2 * Ks + 8 + 3) & ~3;
     const int nch = E >> 3;
@@ -49,7 +51,7 @@ __host__ __device__ inline FCarve fwd_carve(int TEB, int NT, int A, int E, int K
     c.q = o; o += (A + 3) & ~3;
     c.wg = o; o += (A + 3) & ~3;
     c.attp = o; o += c.ATP;
-    c.wc = o; o += Kn * c.WT;
+    c.wc = o;                                             // (the fp32 filter rows of dec_fwd_persist live in the bf16 filter image here)
     c.epart = o; o += NCW * TEB;
     c.e = o; o += TEB;
     c.w = o; o += TEB;
@@ -84,12 +86,14 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
     const FCarve cv_ = fwd_carve(TEB, NT, A, E, Kn, Ks, p.KCP, p.UPW, p.SG2);
     const int WT = cv_.WT, ATP = cv_.ATP, NG = cv_.NG;
     unsigned short* s_cvx = reinterpret_cast<unsigned short*>(smem);                     // [TEB][32] bf16 conv tile of the step, slots {hi | lo | hi}
-    float* s_f = reinterpret_cast<float*>(s_cvx + cv_.cvx_shorts);
+    const ConvGeo cg_ = conv_geo(TEB, Ks);
+    unsigned short* s_ximg = s_cvx + cv_.img;                                           // window image of the attention row, {hi, lo} x 4 shifts
+    unsigned short* s_wimg = s_ximg + 8 * cg_.IMG_LD;                                   // filter image {hi, lo} x 16 rows
+    float* s_f = reinterpret_cast<float*>(s_cvx + cv_.shorts);
     float* s_x2 = s_f + cv_.x2;                                                         // [2][KCP]  ctx_t | h_{t-1} | 0, by step parity
     float* s_q = s_f + cv_.q;                                                           // [A]
     float* s_wg = s_f + cv_.wg;                                                         // [A]
     float* s_attp = s_f + cv_.attp;                                                     // [Ks + NT*TEB + Ks + 8] zero-padded previous attention
-    float* s_wc = s_f + cv_.wc;                                                         // [Kn][WT]
     float* s_epart = s_f + cv_.epart;                                                   // [NCW][TEB] energy partials of the compute waves
     float* s_e = s_f + cv_.e;                                                           // [TEB] masked energies of the tile
     float* s_w = s_f + cv_.w;                                                           // [TEB] exp(e - m)
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
 
     // ---- resident data (small: nothing here scales with the tile but LDS rows)
     for (int i = tid; i < TEB * FCVX_LD; i += blockDim.x) s_cvx[i] = 0;
-    for (int i = tid; i < Kn * WT; i += blockDim.x) { const int k = i / WT, jj = i - k * WT; s_wc[i] = (jj < taps) ? p.w.Wconv[k * taps + jj] : 0.f; }
+    conv_build_wimg(p.w.Wconv, Kn, taps, cg_, s_wimg, tid, blockDim.x);
     for (int i = tid; i < A; i += blockDim.x) s_wg[i] = p.w.wg[i];
     for (int i = tid; i < 2 * p.KCP; i += blockDim.x) s_x2[i] = 0.f;
     {
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
     }
     const int G4 = (NT * TEB) >> 2;                                     // frame groups per utterance in key16t
     const int nch = E >> 3;                                             // 16-byte chunks of an enc row
+    DP_DECL
 
     for (int t = 0; t < L; ++t) {
         int tz = tid, lz_ = lane;
@@ -214,7 +219,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                 }
             }
         }
+        DP_MARK(0)
         __syncthreads();                                                // B1: s_x holds h_{t-1}
+        DP_MARK(1)
         // ---- query slice: outputs q_base + o, two per wave per round, lanes over the reduction
         for (int o0 = 2 * wave; o0 < p.QPW; o0 += 2 * NCW) {
             float acc0 = 0.f, acc1 = 0.f;
@@ -248,64 +255,61 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
             u64* dst = out + (long)NT * p.HG2 + (long)j * p.QG2 + p.QG2 - 1;
             if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
         }
-        // ---- location convolution of the tile from the previous attention row (runs while the query is gathered):
-        //      item = (tap range, kernel, group of 4 frames) with a sliding register window, partial sums meet in LDS
+        DP_MARK(2)
+        // ---- location convolution of the tile from the previous attention row (runs while the query is gathered): a Toeplitz
+        //      product on the matrix cores (decoder_cluster.h::conv_mfma).  A lane ends up with four kernels of one frame: the
+        //      {hi | lo | hi} slots of the sweep's operand row are written straight from the accumulator, so are the values the
+        //      backward pass reads (64-byte runs per kernel)
         {
-            const int ngrp = TEB >> 2;
-            const int nout = Kn * ngrp;
-            int parts = max(1, min(8, (64 * NCW) / nout));
-            parts = max(1, min(parts, cv_.stage_floats / (Kn * TEB)));
-            const int gpp = (WT / 4 + parts - 1) / parts;                // four-tap groups per part
-            float* s_part = s_stage;                                     // free until the S gather of this step
-            for (int it = tz; it < parts * nout; it += 64 * NCW) {
-                const int pz = it / nout, o = it - pz * nout, k = o / ngrp, ig = o - k * ngrp;
-                const int g0 = pz * gpp, g1 = min(WT / 4, g0 + gpp);
-                const float4* wk4 = reinterpret_cast<const float4*>(s_wc) + (k * WT) / 4;
-                const float4* pa4 = reinterpret_cast<const float4*>(s_attp) + tau0 / 4 + ig;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 3
-                for (int g = g0; g < g1; ++g) {
-                    const float4 w4 = wk4[g], lo = pa4[g], hi = pa4[g + 1];
-                    a0 += w4.x * lo.x + w4.y * lo.y + w4.z * lo.z + w4.w * lo.w;
-                    a1 += w4.x * lo.y + w4.y * lo.z + w4.z * lo.w + w4.w * hi.x;
-                    a2 += w4.x * lo.z + w4.y * lo.w + w4.z * hi.x + w4.w * hi.y;
-                    a3 += w4.x * lo.w + w4.y * hi.x + w4.z * hi.y + w4.w * hi.z;
-                }
-                *reinterpret_cast<float4*>(s_part + (long)pz * Kn * TEB + k * TEB + 4 * ig) = make_float4(a0, a1, a2, a3);
-            }
+            conv_build_ximg(s_attp + tau0, ATP - tau0, cg_, s_ximg, tz, 64 * NCW);
             compute_barrier(&s_bar, gen);
-            for (int o = tz; o < Kn * TEB; o += 64 * NCW) {
-                float v = 0.f;
-                for (int pz = 0; pz < parts; ++pz) v += s_part[(long)pz * Kn * TEB + o];
-                const int k = o / TEB, i = o - k * TEB;
-                {
-                    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-                    unsigned short* r = s_cvx + i * FCVX_LD;
-                    r[k] = __builtin_bit_cast(unsigned short, hi); r[KNMAX + k] = __builtin_bit_cast(unsigned short, lo);
-                    r[2 * KNMAX + k] = __builtin_bit_cast(unsigned short, hi);
+            conv_mfma<NCW>(s_ximg, s_wimg, cg_, TEB >> 4, wave, lane, [&](int mt, int n, int q4, const f32x4& acc) {
+                const int i = 16 * mt + n;
+                unsigned short* r = s_cvx + i * FCVX_LD;
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int k0 = 4 * q4 + 2 * pp;
+                    if (k0 < Kn) {
+                        const float v0 = acc[2 * pp], v1 = acc[2 * pp + 1];
+                        const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+                        const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+                        const unsigned hh = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                        const unsigned ll = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                        *reinterpret_cast<unsigned*>(r + k0) = hh;
+                        *reinterpret_cast<unsigned*>(r + KNMAX + k0) = ll;
+                        *reinterpret_cast<unsigned*>(r + 2 * KNMAX + k0) = hh;
+                        if (tau0 + i < Tp) {
+                            p.s.conv[(row * Kn + k0) * Tp + tau0 + i] = v0;
+                            if (k0 + 1 < Kn) p.s.conv[(row * Kn + k0 + 1) * Tp + tau0 + i] = v1;
+                        }
+                    }
                 }
-                if (tau0 + i < Tp) p.s.conv[(row * Kn + k) * Tp + tau0 + i] = v;
-            }
+            });
         }
-        // key fragments of the first KPF 16-frame tiles: requested before the barrier (they do not depend on the query), so the
-        // sweep starts on data that is already there; inside the sweep a fragment is re-requested for tile mt + KPF as soon as
-        // tile mt has consumed it - KPF tiles (8 waves x 64 lanes x 24 B x KPF = 98 KB per CU) in flight against the ~2 us of an
-        // HBM / Infinity-Cache miss at config 5 (one tile ahead left the stream latency-bound: 12 KB in flight, ~6 GB/s per CU)
-        constexpr int KPF = 6;
-        uint2 kr[KPF][FSW_NU];
+        DP_MARK(3)
+        // key fragments of the first KPF pairs of 16-frame tiles: requested before the barrier (they do not depend on the query),
+        // so the sweep starts on data that is already there; inside the sweep a pair's slot is re-requested for pair P + KPF as
+        // soon as pair P has been consumed.  The image holds a lane's two quads of a pair side by side, [pair][q][a][2][4]: one
+        // 16-byte load per (pair, unit) - 8-byte loads reach 0.54 - 0.70 of the 16-byte rate - and 3 pairs x 3 units x 16 B x 512
+        // lanes = 73 KB per CU in flight against the ~2 us of an HBM / Infinity-Cache miss at config 5.
+        constexpr int KPF = 3;
+        uint4 kr[KPF][FSW_NU];
         int acol[FSW_NU];
         const int q_ = lane >> 4, c_ = lane & 15;
 #pragma unroll
         for (int nu = 0; nu < FSW_NU; ++nu) acol[nu] = min(16 * (wave + NCW * nu) + c_, A - 1);
-        const unsigned short* kb0 = p.key16t + (((long)b * G4 + (tau0 >> 2) + q_) * A) * 4;
-        if (MTV > 0) {
+        const int NPR = (TEB + 31) >> 5;                                 // pairs per tile
+        const int NPV = (MTV + 1) >> 1;                                  // pairs that hold a valid frame
+        const unsigned short* kb0 = p.key16t + ((((long)b * NT + j) * NPR * 4 + q_) * A) * 8;      // + (P*4*A + a) * 8
+        if (NPV > 0) {
 #pragma unroll
             for (int u = 0; u < KPF; ++u)
 #pragma unroll
                 for (int nu = 0; nu < FSW_NU; ++nu)
-                    kr[u][nu] = *reinterpret_cast<const uint2*>(kb0 + ((long)4 * min(u, MTV - 1) * A + acol[nu]) * 4);
+                    kr[u][nu] = *reinterpret_cast<const uint4*>(kb0 + ((long)4 * min(u, NPV - 1) * A + acol[nu]) * 8);
         }
         __syncthreads();                                                // B2: s_q holds q_t, s_cvx the tile's conv
+        DP_MARK(4)
         // ---- energies of the tile on the matrix cores, 16 frames at a time
         {
             int opaque = 0;
@@ -314,42 +318,50 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
             float qv[FSW_NU];
 #pragma unroll
             for (int nu = 0; nu < FSW_NU; ++nu) qv[nu] = s_q[acol[nu]];
-            for (int mt0 = 0; mt0 < MTV; mt0 += KPF) {
+            for (int P0 = 0; P0 < NPV; P0 += KPF) {
 #pragma unroll
                 for (int u = 0; u < KPF; ++u) {
-                    const int mt = mt0 + u;
-                    if (mt < MTV) {
-                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(s_cvx + (16 * mt + c) * FCVX_LD + 8 * q);
-                        float ep[4] = {0.f, 0.f, 0.f, 0.f};
+                    const int P = P0 + u;
+                    if (P < NPV) {
 #pragma unroll
-                        for (int nu = 0; nu < FSW_NU; ++nu) {
-                            if (nu < nu_cnt) {
-                                const f32x4 lp = mma16(av, wpx[nu], f32x4{0.f, 0.f, 0.f, 0.f});
-                                const uint2 kb = kr[u][nu];
-                                const float key[4] = {__uint_as_float(kb.x << 16), __uint_as_float(kb.x & 0xffff0000u),
-                                                      __uint_as_float(kb.y << 16), __uint_as_float(kb.y & 0xffff0000u)};
+                        for (int h = 0; h < 2; ++h) {
+                            const int mt = 2 * P + h;
+                            if (mt < MTV) {
+                                const bf16x8 av = *reinterpret_cast<const bf16x8*>(s_cvx + (16 * mt + c) * FCVX_LD + 8 * q);
+                                float ep[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) ep[r] += wgu[nu] * tanh_f(key[r] + qv[nu] + tanh_f(lp[r]));
+                                for (int nu = 0; nu < FSW_NU; ++nu) {
+                                    if (nu < nu_cnt) {
+                                        const f32x4 lp = mma16(av, wpx[nu], f32x4{0.f, 0.f, 0.f, 0.f});
+                                        const unsigned k0 = h ? kr[u][nu].z : kr[u][nu].x, k1 = h ? kr[u][nu].w : kr[u][nu].y;
+                                        const float key[4] = {__uint_as_float(k0 << 16), __uint_as_float(k0 & 0xffff0000u),
+                                                              __uint_as_float(k1 << 16), __uint_as_float(k1 & 0xffff0000u)};
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) ep[r] += wgu[nu] * tanh_f(key[r] + qv[nu] + tanh_f(lp[r]));
+                                    }
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    float v = ep[r];
+#define DPF_STEP(CTRL) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+                                    DPF_STEP(0xB1) DPF_STEP(0x4E) DPF_STEP(0x141) DPF_STEP(0x140)      // sum over the 16 lanes of the row
+#undef DPF_STEP
+                                    if (c == 0) s_epart[wave * TEB + 16 * mt + 4 * q + r] = v;
+                                }
                             }
                         }
-                        if (mt + KPF < MTV) {
+                        if (P + KPF < NPV) {
 #pragma unroll
                             for (int nu = 0; nu < FSW_NU; ++nu)
-                                kr[u][nu] = *reinterpret_cast<const uint2*>(kb0 + ((long)4 * (mt + KPF) * A + acol[nu]) * 4);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = ep[r];
-#define DPF_STEP(CTRL) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-                            DPF_STEP(0xB1) DPF_STEP(0x4E) DPF_STEP(0x141) DPF_STEP(0x140)      // sum over the 16 lanes of the row
-#undef DPF_STEP
-                            if (c == 0) s_epart[wave * TEB + 16 * mt + 4 * q + r] = v;
+                                kr[u][nu] = *reinterpret_cast<const uint4*>(kb0 + ((long)4 * (P + KPF) * A + acol[nu]) * 8);
                         }
                     }
                 }
             }
         }
+        DP_MARK(5)
         compute_barrier(&s_bar, gen);                                   // c3: s_epart complete
+        DP_MARK(6)
         // ---- softmax statistics of the tile: masked energies, (m, s), weights exp(e - m) in LDS
         float m, ssum;
         {
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
 #pragma unroll
             for (int w8 = 0; w8 < NCW; ++w8) ssum += s_red[1][w8];
         }
+        DP_MARK(7)
         // ---- partial context of the tile: sum_f w[f] enc[f, :], the enc rows streamed as 16-byte chunks; thread = (chunk,
         //      frame group), eight rows in flight (61 KB per CU), the frame groups meet in LDS
         {
@@ -430,7 +443,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                 }
             }
         }
+        DP_MARK(8)
         __syncthreads();                                                // B3: s_stage holds every tile's record
+        DP_MARK(9)
         // ---- attention row and context of the utterance (online-softmax combine of the tiles)
         {
             float mi = NEG_BIG, si = 0.f;
@@ -456,21 +471,25 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                 if (c >= c_base && c < c_base + p.CPW) p.s.xin[row * XW + Dd + c] = acc;
             }
         }
+        DP_MARK(10)
         compute_barrier(&s_bar, gen);                                   // c5: s_x holds [ctx_t | h_{t-1}]
-        // ---- LSTM cell: gate rows r = g*UPW + ul of this workgroup, RPW rows per wave, lanes over 16-byte chunks
+        DP_MARK(11)
+        // ---- LSTM cell: gate rows r = g*UPW + ul of this workgroup, RPW rows per wave, lanes over 16-byte chunks; RBS = 8 rows
+        //      per batch of loads (each batch is one exposed L2 round trip: 38 rows per wave at config 5 are 5 batches, not 8)
         {
+            constexpr int RBS = 8;
             const int nchunk = p.KCP >> 3;
             float mine = 0.f;
 #pragma unroll 1
-            for (int bt = 0; bt * RB < RPW; ++bt) {
-                float part[RB];
+            for (int bt = 0; bt * RBS < RPW; ++bt) {
+                float part[RBS];
 #pragma unroll
-                for (int rr = 0; rr < RB; ++rr) part[rr] = 0.f;
+                for (int rr = 0; rr < RBS; ++rr) part[rr] = 0.f;
                 for (int ch0 = lane; ch0 < nchunk; ch0 += 128) {
-                    uint4 wv[RB][2];
+                    uint4 wv[RBS][2];
 #pragma unroll
-                    for (int rr = 0; rr < RB; ++rr) {
-                        const int r = min(wave * RPW + bt * RB + rr, 4 * p.UPW - 1);
+                    for (int rr = 0; rr < RBS; ++rr) {
+                        const int r = min(wave * RPW + bt * RBS + rr, 4 * p.UPW - 1);
                         const int g = r / p.UPW, ul = r - g * p.UPW;
                         const long grow = (long)g * Dd + min(u_base + ul, Dd - 1);
 #pragma unroll
@@ -484,7 +503,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                             const float4 xa = *reinterpret_cast<const float4*>(s_x + 8 * ch);
                             const float4 xb4 = *reinterpret_cast<const float4*>(s_x + 8 * ch + 4);
 #pragma unroll
-                            for (int rr = 0; rr < RB; ++rr) {
+                            for (int rr = 0; rr < RBS; ++rr) {
                                 const uint4 w4 = wv[rr][h2];
                                 part[rr] += __uint_as_float(w4.x << 16) * xa.x + __uint_as_float(w4.x & 0xffff0000u) * xa.y +
                                             __uint_as_float(w4.y << 16) * xa.z + __uint_as_float(w4.y & 0xffff0000u) * xa.w +
@@ -495,15 +514,17 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                     }
                 }
 #pragma unroll
-                for (int rr = 0; rr < RB; ++rr) {
+                for (int rr = 0; rr < RBS; ++rr) {
                     const float sv = wave_sum_dpp(part[rr]);
-                    if (lane == bt * RB + rr) mine = sv;
+                    if (lane == bt * RBS + rr) mine = sv;
                 }
             }
             const int r = wave * RPW + lane;
             if (lane < RPW && r < 4 * p.UPW) s_g[r] = mine + add_r;
         }
+        DP_MARK(12)
         compute_barrier(&s_bar, gen);                                   // c6: s_g holds the gate pre-activations
+        DP_MARK(13)
         if (wave < 2) {                                                 // UPW <= 128 units: thread per unit over two waves
             const int ul = tz, unit = u_base + ul;
             const bool uok = ul < p.UPW && unit < Dd;
@@ -525,6 +546,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
             }
         }
     }
+    DP_DUMP
 }
 
 // key (B, T', A) fp32 -> [B][G4][A][4] bf16, four frames innermost; frames past T' repeat the last row (finite, masked later)
@@ -538,6 +560,30 @@ __global__ void build_key16t_kernel(const float* __restrict__ key, unsigned shor
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = f2bf_bits(key[((long)b * Tp + min(4 * g + r, Tp - 1)) * A + a]);
         *reinterpret_cast<uint2*>(out + 4 * i) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+    }
+}
+
+// forward image of the keys: [B][NT][pairs of 16-frame tiles][q][A][2][4] bf16 - a lane's quads (frames 16 mt + 4 q + r) of the two
+// tiles of a pair side by side; frames past T' repeat the last row (finite, masked later)
+__global__ void build_key16p_kernel(const float* __restrict__ key, unsigned short* __restrict__ out, int B, int Tp, int A, int NT, int TEB) {
+    const int NPR = (TEB + 31) >> 5;
+    const long total = (long)B * NT * NPR * 4 * A;                       // one 16-byte element (pair, q, a) per thread
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(i % A);
+        long r_ = i / A;
+        const int q = (int)(r_ % 4); r_ /= 4;
+        const int P = (int)(r_ % NPR); r_ /= NPR;
+        const int j = (int)(r_ % NT), b = (int)(r_ / NT);
+        unsigned short v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = j * TEB + 16 * (2 * P + h) + 4 * q + r;
+                v[4 * h + r] = f2bf_bits(key[((long)b * Tp + min(f, Tp - 1)) * A + a]);
+            }
+        *reinterpret_cast<uint4*>(out + 8 * i) = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                                            (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
     }
 }
 
@@ -557,13 +603,14 @@ StreamPlanF stream_plan_f(const asr_dec_dims_t& d) {
     pl.KC = d.E + d.Dd; pl.KCP = (pl.KC + 7) & ~7;
     const FCarve c = fwd_carve(pl.TEB, pl.NT, d.A, d.E, d.Kn, d.Ks, pl.KCP, pl.UPW, pl.SG2);
     if (c.NG < 1) return pl;
-    pl.lds = 2 * (size_t)c.cvx_shorts + 4 * (size_t)c.floats;
+    pl.lds = 2 * (size_t)c.shorts + 4 * (size_t)c.floats;
+    if (getenv("ASR_DEC_PLAN_DEBUG")) fprintf(stderr, "[asr] streamed fwd plan B=%d T'=%d: NT=%d TEB=%d UPW=%d LDS=%zu\n", d.B, d.Tp, pl.NT, pl.TEB, pl.UPW, pl.lds);
     if (pl.lds > 156 * 1024) return pl;
     pl.status_bytes = 4096;
     pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.HG2 + pl.QG2 + pl.SG2) * sizeof(u64));
     pl.wcat_bytes = align_up256((size_t)4 * d.Dd * pl.KCP * 2);
     pl.emb_bytes = align_up256((size_t)d.B * d.L * 4 * d.Dd * sizeof(float));
-    pl.key_bytes = align_up256((size_t)d.B * pl.NT * pl.TEB * d.A * 2);
+    pl.key_bytes = align_up256((size_t)d.B * pl.NT * ((pl.TEB + 31) / 32) * 4 * d.A * 16);      // pair image (odd tile counts are padded)
     pl.total = pl.status_bytes + pl.xbuf_bytes + pl.wcat_bytes + pl.emb_bytes + pl.key_bytes;
     pl.ok = true;
     return pl;
@@ -589,7 +636,7 @@ int dec_fwd_streamed(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const 
     unsigned short* key16t = (unsigned short*)(base + pl.status_bytes + pl.xbuf_bytes + pl.wcat_bytes + pl.emb_bytes);
     clear_work(work, pl.xbuf_bytes, st);
     hipLaunchKernelGGL(build_wcat16_kernel, dim3(512), dim3(256), 0, st, w.Wih[0], w.Whh[0], wcat16, 4 * d.Dd, d.Dd, d.E, pl.KCP);
-    hipLaunchKernelGGL(build_key16t_kernel, dim3(1024), dim3(256), 0, st, s.key, key16t, d.B, d.Tp, d.A, pl.NT * pl.TEB / 4);
+    hipLaunchKernelGGL(build_key16p_kernel, dim3(1024), dim3(256), 0, st, s.key, key16t, d.B, d.Tp, d.A, pl.NT, pl.TEB);
     const int XW = d.Dd + d.E;
     int rc = asr_gemm(s.xin, w.Wih[0], embproj, nullptr, d.B * d.L, 4 * d.Dd, d.Dd, XW, XW, 4 * d.Dd, 1, 1, ASR_ACT_NONE, 0, 1, 1, 0, 0, 0,
                       0, 0, ASR_BF16, (asr_stream_t)st);
@@ -666,7 +713,7 @@ __host__ __device__ inline SBCarve sbwd_carve(int TEB, int A, int E, int Kn, int
     c.DW = (c.PADL + TEB + Ks + 8 + 3) & ~3;            // zero-padded dconv window of the tile: frames tau0 - PADL ..
     if (((c.DW >> 2) & 1) == 0) c.DW += 4;
     c.WT = (2 * Ks + 1 + 3) & ~3;
-    const int nitem = Kn * (TEB >> 2);
+    const int nitem = Kn * (TEB >> 4);                   // (kernel, 16-frame group) items of the transposed convolution
     c.parts = nct / nitem; if (c.parts > 4) c.parts = 4; if (c.parts < 1) c.parts = 1;
     int o = 0;
     c.dl = o; o += 16 * SW_MT * c.AP;
@@ -1088,6 +1135,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
     }
     const int FPP = nct >> 3;                                           // frames per pass of P2 (8 threads per frame)
     const int NATT = (Tp + nct - 1) / nct;                              // attention-row elements per thread (<= 6 by the plan)
+    DP_DECL
 
     for (int t = L - 1; t >= 0; --t) {
         int tz = tid, lz_ = lane;
@@ -1097,6 +1145,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
         const long row = (long)b * L + t;
         const u64 want = pair_want(seq_of(s), epoch_);
         u64* out = xb(s & 1);
+        DP_MARK(0)
         // ---- S1: cell backward of ALL hidden units (thread per unit; every workgroup of the cluster computes the same)
         {
             float dh = pdh;
@@ -1115,11 +1164,15 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
                 go[0] = d0; go[Dd] = d1; go[2 * Dd] = d2; go[3 * Dd] = d3;
             }
         }
+        DP_MARK(1)
         __syncthreads();                                                // Ba
+        DP_MARK(2)
         // ---- P1: dctx slice and the recurrent part of dh_{t-1} for the own units
         if (RESIDENT) { DPB_P1((RESIDENT ? RCB : 1), wave, ncw) }
         DSB_P1_EXTRA(wave, nw)
+        DP_MARK(3)
         __syncthreads();                                                // Bb
+        DP_MARK(4)
         // ---- C record {dctx slice | dh_rec slice} + global dxin (context part)
         for (int i2 = tz; i2 < p.CG2; i2 += nct) {
             float v[2];
@@ -1156,7 +1209,9 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
         const int cvk1 = min(cvi1, Kn * GF - 1) / GF, cvf1 = min(cvi1, Kn * GF - 1) - cvk1 * GF;
         const float c0 = p.s.conv[(row * Kn + cvk0) * Tp + min(tau0 + cvf0, Tp - 1)];
         const float c1 = p.s.conv[(row * Kn + cvk1) * Tp + min(tau0 + cvf1, Tp - 1)];
+        DP_MARK(5)
         __syncthreads();                                                // H2: s_crec holds the C records of all workgroups
+        DP_MARK(6)
         // ---- P2: dot over the utterance, dattn of the tile's valid frames, de
         {
             for (int e = tz; e < E; e += nct) { const int i = e / p.CPW; s_dcx[e] = s_crec[i * CG2f + (e - i * p.CPW)]; }
@@ -1220,6 +1275,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
             for (int f = nf + tz; f < NDE; f += nct) s_de[f] = 0.f;     // frames past the utterance (and what P5 left there)
         }
         __syncthreads();                                                // X1: s_de, s_cvx, s_cvT complete (the polling waves join the sweep)
+        DP_MARK(7)
         // ---- P3 / P4: energy backward sweep and dconv of every 48-frame group, then this wave's query-gradient partials (Q record)
         {
             float dqt[SW_NU];
@@ -1239,7 +1295,9 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
                 }
             }
         }
+        DP_MARK(8)
         __syncthreads();                                                // H3: dq partials of all workgroups, the dconv window
+        DP_MARK(10)
         // ---- P5: dq (sum over tiles), its part of dh_{t-1}, datt_next of the tile
         {
             float dqv = 0.f;
@@ -1250,7 +1308,9 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
         }
         if (t > 0) {
             // datt_next[tau'] = sum_k sum_jj W_conv[k][jj] * dconv[k][tau' - jj + Ks] for the tile's frames (window-relative rows)
-            const int ngrp = TEB >> 2;
+            // item = (tap range, kernel, group of 16 frames): 64 FMAs per filter read + five window reads.  (With 4 frames per item
+            // as in dec_bwd_persist a read fed 5 FMAs, and the 384-frame tile of config 5 was bound by the LDS port.)
+            const int ngrp = TEB >> 4;
             const int nitem = Kn * ngrp;
             const int parts = cv_.parts;
             const int gpp = (WT / 4 + parts - 1) / parts;
@@ -1258,19 +1318,25 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
                 const int pz = it / nitem, o = it - pz * nitem, k = o / ngrp, ig = o - k * ngrp;
                 const int g0 = pz * gpp, g1 = min(WT / 4, g0 + gpp);
                 const float4* wk4 = reinterpret_cast<const float4*>(s_wc) + (k * WT) / 4;
-                const float4* q4 = reinterpret_cast<const float4*>(s_dcp) + (k * DW + PADL + Ks) / 4 + ig;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 3
+                const float4* q4 = reinterpret_cast<const float4*>(s_dcp) + (k * DW + PADL + Ks) / 4 + 4 * ig;
+                float acc[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 2
                 for (int g = g0; g < g1; ++g) {
                     const float4 w4 = wk4[g];
-                    const float4 lo = q4[-g - 1];
-                    const float4 hi = q4[-g];
-                    a0 += w4.x * hi.x + w4.y * lo.w + w4.z * lo.z + w4.w * lo.y;
-                    a1 += w4.x * hi.y + w4.y * hi.x + w4.z * lo.w + w4.w * lo.z;
-                    a2 += w4.x * hi.z + w4.y * hi.y + w4.z * hi.x + w4.w * lo.w;
-                    a3 += w4.x * hi.w + w4.y * hi.z + w4.z * hi.y + w4.w * hi.x;
+                    float qq[20];
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) {
+                        const float4 t4 = q4[v - 1 - g];
+                        qq[4 * v] = t4.x; qq[4 * v + 1] = t4.y; qq[4 * v + 2] = t4.z; qq[4 * v + 3] = t4.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] += w4.x * qq[i + 4] + w4.y * qq[i + 3] + w4.z * qq[i + 2] + w4.w * qq[i + 1];
                 }
-                *reinterpret_cast<float4*>(s_pt + (long)(pz * Kn + k) * TEB + 4 * ig) = make_float4(a0, a1, a2, a3);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    *reinterpret_cast<float4*>(s_pt + (long)(pz * Kn + k) * TEB + 16 * ig + 4 * v) = make_float4(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
             }
             cbar(&s_bar, gen, ncw);                                     // s_dq, s_pt complete
             // query part of dh_{t-1}: sum_a dq[a] * W_q[a][unit] for the own units, rows of W_q^T streamed three at a time
@@ -1324,8 +1390,11 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
             pcp = (t > 1) ? p.s.cs[(r1 - 1) * Dd + uc] : 0.f;
             pdh = p.dhs[r1 * Dd + uc];
         }
+        DP_MARK(11)
         __syncthreads();                                                // H4: s_nrec holds the N records for the next step
+        DP_MARK(12)
     }
+    DP_DUMP
     {   // results accumulated on chip: d w_g, d W_proj of the wave's units -> the workgroup's slot
         float* sl_ = p.slots + ((long)b * NT + j) * p.slot;
 #pragma unroll
@@ -1374,6 +1443,7 @@ StreamPlanB stream_plan_b(const asr_dec_dims_t& d) {
     pl.CG2 = even((pl.CPW + pl.UPW + 1) / 2); pl.QG2 = even(d.A / 2); pl.VG2 = even((pl.TEB * d.Kn + 1) / 2); pl.NG2 = even((pl.TEB + pl.UPW + 1) / 2);
     const SBCarve cv = sbwd_carve(pl.TEB, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.CPW, pl.CG2, pl.QG2, pl.NG2);
     pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
+    if (getenv("ASR_DEC_PLAN_DEBUG")) fprintf(stderr, "[asr] streamed bwd plan B=%d T'=%d: NT=%d TEB=%d UPW=%d LDS=%zu\n", d.B, d.Tp, pl.NT, pl.TEB, pl.UPW, pl.lds);
     if (pl.lds > 160 * 1024 - 4096) return pl;
     pl.status_bytes = 4096;
     pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.CG2 + pl.QG2 + pl.VG2 + pl.NG2) * sizeof(u64));

@@ -48,6 +48,15 @@ class Encoder(nn.Module):
             if vgg == 1:
                 from src.vgg import VGGExtractor
                 ext = VGGExtractor(input_size)
+            elif vgg == 2:
+                from src.vgg import FreqVGGExtractor
+                ext = FreqVGGExtractor(input_size, vgg_freq, vgg_low_filt)
+            elif vgg == 3:
+                from src.vgg import VGGExtractor2
+                ext = VGGExtractor2(input_size)
+            elif vgg == 4:
+                from src.vgg import FreqVGGExtractor2
+                ext = FreqVGGExtractor2(input_size, vgg_freq, vgg_low_filt)
             elif vgg == 5:
                 from src.vgg import VGGExtractor_LN
                 ext = VGGExtractor_LN(input_size)
@@ -58,7 +67,7 @@ class Encoder(nn.Module):
             layers.append(ext)
             input_dim = ext.out_dim
             self.sample_rate = self.sample_rate * (4 if (vgg < 3 or vgg == 6) else 2)
-        if module not in ('LSTM',):
+        if module not in ('LSTM', 'GRU'):
             raise NotImplementedError('encoder module %s is not available on the HIP path' % module)
         for l in range(len(dim)):
             layers.append(RNNLayer(input_dim, module, dim[l], bidirection, dropout[l], layer_norm[l], sample_rate[l],
@@ -73,9 +82,9 @@ class Encoder(nn.Module):
             H.begin_forward()
             # CU split between the recurrence stream and the side stream follows the widest recurrent layer of THIS model
             # (eval-mode forwards are followed by backward passes too: tests, gradient checks)
-            H.configure_rec_units([m.dim for m in self.layers if isinstance(m, RNNLayer)])
+            H.configure_rec_units([m.dim for m in self.layers if isinstance(m, RNNLayer) and m.module == 'LSTM'] or [320])
         if self.training and ctx is not None and input_x.is_cuda:
-            F_hip.prepack16([m for m in self.layers if isinstance(m, RNNLayer)], input_x.shape[0], ctx.prec)
+            F_hip.prepack16([m for m in self.layers if isinstance(m, RNNLayer) and m.module == 'LSTM'], input_x.shape[0], ctx.prec)
         for layer in self.layers:
             input_x, enc_len = layer(input_x, enc_len, ctx)
         return input_x, enc_len
@@ -86,15 +95,14 @@ class Decoder(nn.Module):
 
     def __init__(self, batch_size, input_dim, vocab_size, module, dim, layer, dropout):
         super().__init__()
-        if module != 'LSTM':
+        if module not in ('LSTM', 'GRU'):
             raise NotImplementedError('decoder module %s is not available on the HIP path' % module)
-        if dropout != 0:
-            raise NotImplementedError('decoder dropout > 0 is not available on the HIP path')
-        if layer > H.MAX_DEC_LAYERS:
-            raise NotImplementedError('at most %d decoder layers' % H.MAX_DEC_LAYERS)
+        from src.variants import RNNParams
         self.in_dim, self.layer, self.dim, self.dropout = input_dim, layer, dim, dropout
-        self.enable_cell = True
-        self.layers = LSTMParams(input_dim, dim, False, num_layers=layer)
+        self.enable_cell = module == 'LSTM'
+        self.layers = RNNParams(module, input_dim, dim, False, num_layers=layer)
+        # the persistent / per-step decoder kernels cover the shipped shape of this module; the rest runs in src/variants.py
+        self.fast = module == 'LSTM' and dropout == 0 and layer <= H.MAX_DEC_LAYERS
         self.char_trans = nn.Linear(dim, vocab_size)
         self.hidden_state = None
 
@@ -105,11 +113,20 @@ class Attention(nn.Module):
     def __init__(self, v_dim, q_dim, mode, dim, num_head, temperature, v_proj, loc_kernel_size, loc_kernel_num):
         super().__init__()
         self.v_dim, self.dim, self.mode, self.num_head, self.v_proj = v_dim, dim, mode.lower(), num_head, v_proj
-        if self.mode != 'loc' or num_head != 1 or v_proj:
-            raise NotImplementedError("HIP path implements mode='loc', num_head=1, v_proj=False")
         self.proj_q = nn.Linear(q_dim, dim * num_head)
         self.proj_k = nn.Linear(v_dim, dim * num_head)
-        self.att_layer = LocationAwareAttention(loc_kernel_size, loc_kernel_num, dim, num_head, temperature)
+        if v_proj:
+            self.proj_v = nn.Linear(v_dim, v_dim * num_head)
+        if self.mode == 'dot':
+            from src.variants import ScaleDotAttention
+            self.att_layer = ScaleDotAttention(temperature, num_head)
+        elif self.mode == 'loc':
+            self.att_layer = LocationAwareAttention(loc_kernel_size, loc_kernel_num, dim, num_head, temperature)
+        else:
+            raise NotImplementedError
+        if num_head > 1:
+            self.merge_head = nn.Linear(v_dim * num_head, v_dim)
+        self.fast = self.mode == 'loc' and num_head == 1 and not v_proj
 
 
 class ASR(nn.Module):
@@ -119,8 +136,7 @@ class ASR(nn.Module):
                  init_adadelta=True, prec='bf16', seed=0):
         super().__init__()
         assert 0 <= ctc_weight <= 1
-        if emb_drop != 0.0:
-            raise NotImplementedError('emb_drop > 0 is not available on the HIP path')
+        self.emb_drop = float(emb_drop)
         self.vocab_size = vocab_size
         self.ctc_weight = ctc_weight
         self.enable_ctc = ctc_weight > 0
@@ -280,6 +296,15 @@ class ASR(nn.Module):
                 ctc_output = F_hip.CTCHeadFn.apply(ctx.anchor, encode_feature, self.ctc_layer[0], self.prec, get_logit)
         if self.enable_att:
             L = int(decode_step)
+            if not (self.decoder.fast and self.attention.fast and self.emb_drop == 0.0):
+                from src.variants import variant_decoder
+                att_output, att_seq, hs = variant_decoder(self, ctx.anchor, encode_feature, encode_len, L, teacher,
+                                                          float(tf_rate) if teacher is not None else 1.0, ctx)
+                if get_dec_state:
+                    dec_state = hs
+                if side_ctc and not ctc_async:
+                    H.join_branch(ctc_output)
+                return ctc_output, encode_len, att_output, att_seq, dec_state
             att_output, att_seq, hs = F_hip.AttDecoderFn.apply(ctx.anchor, encode_feature, encode_len, teacher, L, self, self.prec,
                                                                float(tf_rate) if teacher is not None else 1.0)
             if get_dec_state:

@@ -99,6 +99,18 @@ SIGNATURES = {
     'asr_ctc_prefix_score': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'asr_lstm_cell': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     'asr_gather_rows': [_vp, _vp, _vp, _i, _i, _l, _l, _i, _vp],
+    'asr_masked_softmax_fwd': [_vp, _vp, _i, _i, _i, _f, _vp, _vp],
+    'asr_masked_softmax_bwd': [_vp, _vp, _i, _i, _f, _vp, _vp],
+    'asr_loc_energy_fwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    'asr_loc_energy_bwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    'asr_loc_conv_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    'asr_loc_conv_bwd': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    'asr_lstm_cell_fwd': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    'asr_lstm_cell_bwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    'asr_gru_cell_fwd': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    'asr_gru_cell_bwd': [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    'asr_gru_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    'asr_gru_bwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     'asr_sumsq': [_vp, _l, _vp, _vp],
     'asr_scale': [_vp, _l, _f, _vp],
     'asr_adadelta_step': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp],

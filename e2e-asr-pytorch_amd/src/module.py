@@ -4,7 +4,7 @@
 The nn.Modules here only OWN parameters; all arithmetic goes through the HIP kernels via
 src/functions.py.  Supported on the MI355X path: RNNLayer (LSTM, uni/bidirectional, LayerNorm, dropout,
 'drop'/'concat' down-sampling, projection), Downsampler (vgg 6), VGGExtractor (vgg 1), VGGExtractor_LN
-(vgg 5), LocationAwareAttention (num_head 1).
+(vgg 5), LocationAwareAttention; GRU layers and the other attention variants: src/variants.py.
 """
 import torch
 import torch.nn as nn
@@ -35,15 +35,20 @@ class RNNLayer(nn.Module):
 
     def __init__(self, input_dim, module, dim, bidirection, dropout, layer_norm, sample_rate, sample_style, proj, batch_size=None):
         super().__init__()
-        if module.upper() != 'LSTM':
-            raise NotImplementedError('HIP path implements the LSTM encoder cell only (got %s)' % module)
+        if module.upper() not in ('LSTM', 'GRU'):
+            raise NotImplementedError('HIP path implements LSTM and GRU encoder cells (got %s)' % module)
+        self.module = module.upper()
         if sample_style not in ('drop', 'concat'):
             raise ValueError('Unsupported Sample Style: ' + sample_style)
         self.dim, self.nd = dim, (2 if bidirection else 1)
         rnn_out_dim = self.nd * dim
         self.out_dim = sample_rate * rnn_out_dim if (sample_rate > 1 and sample_style == 'concat') else rnn_out_dim
         self.dropout, self.layer_norm, self.sample_rate, self.sample_style, self.proj = dropout, layer_norm, sample_rate, sample_style, proj
-        self.layer = LSTMParams(input_dim, dim, bidirection)
+        if self.module == 'LSTM':
+            self.layer = LSTMParams(input_dim, dim, bidirection)
+        else:
+            from src.variants import RNNParams
+            self.layer = RNNParams('GRU', input_dim, dim, bidirection)     # persistent kernels are LSTM-only: src/variants.py
         if layer_norm:
             self.ln = nn.LayerNorm(rnn_out_dim)
         if proj:
@@ -79,7 +84,10 @@ class RNNLayer(nn.Module):
     def forward(self, input_x, x_len, ctx=None):
         train = self.training and self.dropout > 0
         seed = ctx.next_seed() if (ctx is not None and train) else 0
-        if F_hip.rnn_fast_ok(self, input_x, ctx.prec):
+        if self.module == 'GRU':
+            from src.variants import gru_layer_forward
+            out = gru_layer_forward(self, input_x, ctx, train, seed)
+        elif F_hip.rnn_fast_ok(self, input_x, ctx.prec):
             out = F_hip.RNNLayerFastFn.apply(ctx.anchor, input_x, self, train, seed)       # bf16 out
         else:
             out = F_hip.RNNLayerFn.apply(ctx.anchor, F_hip.to_f32_fn(input_x), self, train, seed, ctx.prec)
@@ -111,8 +119,6 @@ class LocationAwareAttention(nn.Module):
 
     def __init__(self, kernel_size, kernel_num, dim, num_head, temperature):
         super().__init__()
-        if num_head != 1:
-            raise NotImplementedError('HIP path implements num_head == 1')
         self.kernel_size, self.kernel_num, self.dim, self.num_head, self.temperature = kernel_size, kernel_num, dim, num_head, temperature
         self.loc_conv = nn.Conv1d(num_head, kernel_num, kernel_size=2 * kernel_size + 1, padding=kernel_size, bias=False)
         self.loc_proj = nn.Linear(kernel_num, dim, bias=False)

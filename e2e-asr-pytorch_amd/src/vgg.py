@@ -27,13 +27,18 @@ class _VGGFn(torch.autograd.Function):
     def forward(ctx, anchor, feature, mod, prec):
         st = H.stream_ptr()
         dev = feature.device
-        if feature.shape[1] % 4 != 0:
-            feature = feature[:, :-(feature.shape[1] % 4), :]
+        div = getattr(mod, 'time_div', 4)
+        if feature.shape[1] % div != 0:
+            feature = feature[:, :-(feature.shape[1] % div), :]
+        fs = getattr(mod, 'freq_slice', None)
+        if fs is not None:                       # one band of a frequency-split extractor: columns f0..f1 of every channel (a copy)
+            feature = feature.reshape(feature.shape[0], feature.shape[1], mod.in_channel, -1)[..., fs[0]:fs[1]]
         feature = feature.contiguous()
-        B, T, _ = feature.shape
+        B, T = feature.shape[0], feature.shape[1]
         Cin, F = mod.in_channel, mod.freq_dim
         x = _e((B, T, F, Cin), dev)
         H.call('asr_permute_last2', H.ptr(feature), H.ptr(x), B * T, Cin, F, st)      # (.., C, F) -> (.., F, C)
+        freq_only2 = getattr(mod, 'pool2_freq_only', False)
         saved = {'x': [], 'pre': [], 'stats': [], 'idx': [], 'dims': []}
         cur, t, f = x, T, F
         for li, (conv, ln) in enumerate(mod.conv_layers()):
@@ -53,7 +58,15 @@ class _VGGFn(torch.autograd.Function):
                 stats = _e((B * t * Co, 2), dev)
                 H.call('asr_ln_freq_fwd', H.ptr(out), H.ptr(ln.weight), H.ptr(ln.bias), H.ptr(act), H.ptr(stats), B * t, f, Co, 1e-5, 1, st)
                 saved['pre'].append(out); saved['stats'].append(stats)
-            if li in (1, 3):
+            if li == 3 and freq_only2:
+                # MaxPool2d((1, 2)): the 2 x 2 kernel on the image seen as B*t images of ONE row
+                f2 = f // 2
+                pooled = _e((B, t, f2, Co), dev)
+                idx = _e((B, t, f2, Co), dev, torch.uint8)
+                H.call('asr_maxpool2x2_fwd', H.ptr(act), H.ptr(pooled), H.ptr(idx), B * t, 1, f, Co, 1, f2, st)
+                saved['idx'].append((idx, act, t, f, t, f2))
+                cur, f = pooled, f2
+            elif li in (1, 3):
                 t2, f2 = ((t + 1) // 2, (f + 1) // 2) if mod.ceil_mode else (t // 2, f // 2)
                 pooled = _e((B, t2, f2, Co), dev)
                 idx = _e((B, t2, f2, Co), dev, torch.uint8)
@@ -87,7 +100,10 @@ class _VGGFn(torch.autograd.Function):
             if sv['idx'][li] is not None:
                 idx, act, tt, ff, t2, f2 = sv['idx'][li]
                 gp = _e((B, tt, ff, Co), dev)
-                H.call('asr_maxpool2x2_bwd', H.ptr(g), H.ptr(idx), H.ptr(gp), B, tt, ff, Co, t2, f2, st)
+                if t2 == tt and li == 3 and getattr(mod, 'pool2_freq_only', False):
+                    H.call('asr_maxpool2x2_bwd', H.ptr(g), H.ptr(idx), H.ptr(gp), B * tt, 1, ff, Co, 1, f2, st)
+                else:
+                    H.call('asr_maxpool2x2_bwd', H.ptr(g), H.ptr(idx), H.ptr(gp), B, tt, ff, Co, t2, f2, st)
                 g = gp
             act = sv['act'][li]
             dpre = _e((B, t_l, f_l, Co), dev)
@@ -107,7 +123,12 @@ class _VGGFn(torch.autograd.Function):
                 gin = _e((B, t_l, f_l, Ci), dev)
                 H.call('asr_conv3x3', H.ptr(dpre), H.ptr(wd), H.ptr(gin), None, B, t_l, f_l, Co, Ci, 0, H.ACT_NONE, 0, prec, st)
                 g = gin
-        if mod.dp is not None:
+        owner = getattr(mod, 'owner', None)
+        if owner is not None:                    # a band of a frequency-split extractor: the bucket goes when both bands are done
+            owner._bands_done += 1
+            if owner._bands_done == 2 and owner.dp is not None:
+                owner.dp.bucket_ready(owner.bucket)
+        elif mod.dp is not None:
             mod.dp.bucket_ready(mod.bucket)
         ctx.saved = None
         return None, None, None, None
@@ -294,3 +315,78 @@ class VGGExtractor_LN(_VGGBase):
 
     def conv_layers(self):
         return [(self.extractor[i], self.extractor[i + 1].layer_norm) for i in (0, 3, 7, 10)]
+
+
+class VGGExtractor2(_VGGBase):
+    """VGG extractor that halves time once (reference src/module.py:843-905): 64 / 128 channels, floor-mode 2 x 2 pooling,
+    then MaxPool2d((1, 2)) - frequency only."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.init_dim, self.hide_dim, self.ceil_mode = 64, 128, False
+        self.time_div, self.pool2_freq_only = 2, True
+        self.in_channel, self.freq_dim, self.out_dim = self.check_dim(input_dim)
+        self.dp, self.bucket = None, None
+        self.extractor = nn.Sequential(
+            nn.Conv2d(self.in_channel, self.init_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.Conv2d(self.init_dim, self.init_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d(2, stride=2),
+            nn.Conv2d(self.init_dim, self.hide_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.Conv2d(self.hide_dim, self.hide_dim, 3, stride=1, padding=1), nn.ReLU(),
+            nn.MaxPool2d((1, 2), stride=(1, 2)))
+
+    def conv_layers(self):
+        return [(self.extractor[i], None) for i in (0, 2, 5, 7)]
+
+    def forward(self, feature, feat_len, ctx=None):
+        return _VGGFn.apply(ctx.anchor, feature, self, ctx.prec), feat_len // 2
+
+
+class _Band(object):
+    """One band (low / high frequencies) of a frequency-split extractor as _VGGFn sees it."""
+
+    def __init__(self, owner, seq, in_channel, f0, f1, time_div, pool2_freq_only):
+        self.owner, self.seq, self.in_channel, self.freq_slice, self.freq_dim = owner, seq, in_channel, (f0, f1), f1 - f0
+        self.time_div, self.pool2_freq_only, self.ceil_mode, self.dp, self.bucket = time_div, pool2_freq_only, False, None, None
+
+    def conv_layers(self):
+        return [(self.seq[i], None) for i in (0, 2, 5, 7)]
+
+
+class FreqVGGExtractor(nn.Module):
+    """Frequency-split VGG (reference src/module.py:746-841; `pool2_freq_only` = FreqVGGExtractor2, :907-1001): the bins below
+    `split_freq` go through a narrow stack (low_dim, 2 low_dim channels), the rest through a wide one (64 - low_dim,
+    128 - 2 low_dim); the two outputs are concatenated."""
+
+    def __init__(self, input_dim, split_freq, low_dim=4, pool2_freq_only=False):
+        super().__init__()
+        if input_dim % FBANK_SIZE != 0:
+            raise ValueError('HIP VGG front-end expects 40-bin fbank channels (input dim %d)' % input_dim)
+        self.split_freq, self.in_channel, self.freq_dim = split_freq, input_dim // FBANK_SIZE, FBANK_SIZE
+        assert split_freq % 4 == 0 and 0 < split_freq < self.freq_dim
+        li, lh, hi, hh = low_dim, 2 * low_dim, 64 - low_dim, 128 - 2 * low_dim
+        self.low_out_dim, self.high_out_dim = split_freq // 4 * lh, (self.freq_dim - split_freq) // 4 * hh
+        self.out_dim = self.low_out_dim + self.high_out_dim
+        self.time_div = 2 if pool2_freq_only else 4
+        self.dp, self.bucket, self._bands_done = None, None, 0
+        last = (lambda: nn.MaxPool2d((1, 2), stride=(1, 2))) if pool2_freq_only else (lambda: nn.MaxPool2d(2, stride=2))
+
+        def stack(c1, c2):
+            return nn.Sequential(nn.Conv2d(self.in_channel, c1, 3, stride=1, padding=1), nn.ReLU(),
+                                 nn.Conv2d(c1, c1, 3, stride=1, padding=1), nn.ReLU(), nn.MaxPool2d(2, stride=2),
+                                 nn.Conv2d(c1, c2, 3, stride=1, padding=1), nn.ReLU(),
+                                 nn.Conv2d(c2, c2, 3, stride=1, padding=1), nn.ReLU(), last())
+        self.low_extractor, self.high_extractor = stack(li, lh), stack(hi, hh)
+        self._bands = (_Band(self, self.low_extractor, self.in_channel, 0, split_freq, self.time_div, pool2_freq_only),
+                       _Band(self, self.high_extractor, self.in_channel, split_freq, self.freq_dim, self.time_div, pool2_freq_only))
+
+    def forward(self, feature, feat_len, ctx=None):
+        self._bands_done = 0
+        lo = _VGGFn.apply(ctx.anchor, feature, self._bands[0], ctx.prec)
+        hi = _VGGFn.apply(ctx.anchor, feature, self._bands[1], ctx.prec)
+        return torch.cat((lo, hi), dim=-1), feat_len // self.time_div
+
+
+class FreqVGGExtractor2(FreqVGGExtractor):
+    def __init__(self, input_dim, split_freq, low_dim=4):
+        super().__init__(input_dim, split_freq, low_dim, pool2_freq_only=True)

@@ -404,6 +404,46 @@ int asr_ln_freq_bwd(const float* dy, const float* x, const float* w, const float
 int asr_permute_last2(const float* in, float* out, long rows, int A, int Bd, asr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Model variants outside the shipped configs (csrc/variants.hip, composed step by step by src/variants.py
+ * as the reference's own Python loop does, src/asr.py:131-170).  All fp32, all row-major.
+ *   asr_masked_softmax_fwd/bwd : BaseAttention._attend (src/module.py:1110-1118): attn = softmax(energy / temperature) over
+ *                                t < len[row / NH], exactly 0 beyond; rows = B * NH ordered b * NH + head (src/module.py:1107).
+ *   asr_loc_energy_fwd/bwd     : LocationAwareAttention.forward (src/module.py:1176-1182) for any num_head:
+ *                                energy[r,t] = gen_energy(tanh(key[r,t,:] + q[r,:] + tanh(loc_pre[r / NH,t,:]))); loc_pre (B,T,D) is the
+ *                                loc_proj output BEFORE its tanh.  bwd: dkey += (same key at every decoder step), dq / dloc_pre written,
+ *                                dwg / dbg += (parameter gradients).
+ *   asr_loc_conv_fwd/bwd       : loc_conv = nn.Conv1d(NH, Kn, 2 Ks + 1, padding Ks, bias False) on prev_att (B,NH,T), output already
+ *                                transposed to (B,T,Kn) (src/module.py:1176); bwd: dprev written (may be NULL), dW +=.
+ *   asr_lstm_cell_fwd/bwd      : nn.LSTM cell on gx + gh (both (N,4D), biases inside; gate order i,f,g,o) with its backward
+ *                                (decoder layers, src/asr.py:204,262); act (N,4D) = activated gates, dgates (N,4D) serves both halves.
+ *   asr_gru_cell_fwd/bwd       : nn.GRU cell (decoder module GRU, src/asr.py:203-204): gi, gh (N,3D) gate order r,z,n; saved (N,4D) =
+ *                                r | z | n | gh_n; bwd: dgi, dgh (N,3D) and the direct part of dh_prev (= dh * z).
+ *   asr_gru_fwd/bwd            : nn.GRU(bidirectional, batch_first) time recurrence of an encoder layer (src/module.py:1023,1049; zero
+ *                                initial state, padded frames processed like the reference does): gi (B,T,ND,3H) = x W_ih^T + b_ih,
+ *                                whhT (ND,H,3H) = weight_hh transposed, bhh (ND,3H); y (B,T,ND*H); saved (B,T,ND,4H).
+ *                                bwd: whh (ND,3H,H) as stored; dgi / dgh (B,T,ND,3H) from which the caller forms dW_ih, db_ih, dx and
+ *                                dW_hh (shifted rows, asr_gemm seqT), db_hh.
+ */
+int asr_masked_softmax_fwd(const float* energy, const int64_t* len, int rows, int NH, int T, float temperature, float* attn, asr_stream_t stream);
+int asr_masked_softmax_bwd(const float* attn, const float* dattn, int rows, int T, float temperature, float* denergy, asr_stream_t stream);
+int asr_loc_energy_fwd(const float* key, const float* q, const float* loc_pre, const float* wg, const float* bg,
+                       int B, int NH, int T, int D, float* energy, asr_stream_t stream);
+int asr_loc_energy_bwd(const float* key, const float* q, const float* loc_pre, const float* wg, const float* denergy,
+                       int B, int NH, int T, int D, float* dkey, float* dq, float* dloc_pre, float* dwg, float* dbg, asr_stream_t stream);
+int asr_loc_conv_fwd(const float* prev_att, const float* W, int B, int NH, int T, int Kn, int Ks, float* out, asr_stream_t stream);
+int asr_loc_conv_bwd(const float* dout, const float* prev_att, const float* W, int B, int NH, int T, int Kn, int Ks,
+                     float* dprev, float* dW, asr_stream_t stream);
+int asr_lstm_cell_fwd(const float* gx, const float* gh, const float* c_prev, int N, int D, float* act, float* h, float* c, asr_stream_t stream);
+int asr_lstm_cell_bwd(const float* act, const float* c_prev, const float* c, const float* dh, const float* dc, int N, int D,
+                      float* dgates, float* dc_prev, asr_stream_t stream);
+int asr_gru_cell_fwd(const float* gi, const float* gh, const float* h_prev, int N, int D, float* saved, float* h, asr_stream_t stream);
+int asr_gru_cell_bwd(const float* saved, const float* h_prev, const float* dh, int N, int D, float* dgi, float* dgh, float* dh_prev,
+                     asr_stream_t stream);
+int asr_gru_fwd(const float* gi, const float* whhT, const float* bhh, int B, int T, int H, int ND, float* y, float* saved, asr_stream_t stream);
+int asr_gru_bwd(const float* dy, const float* y, const float* saved, const float* whh, int B, int T, int H, int ND,
+                float* dgi, float* dgh, asr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Beam-search inference (BeamDecoder.forward src/decode.py:65-183), batched over live hypotheses.
  *   asr_att_decoder_keys : key = tanh(proj_k(enc)) once per utterance (src/asr.py:345).
  *   asr_att_decoder_step : ONE decode step t for all dims->B rows of `state` (each row = one hypothesis at step t):

@@ -37,6 +37,8 @@ class ModelCfg(object):
         self.enable_ctc = self.ctc_weight > 0
         self.enable_att = self.ctc_weight != 1
         self.vgg = int(enc['vgg'])
+        self.vgg_freq = int(enc.get('vgg_freq', -1))
+        self.vgg_low_filt = int(enc.get('vgg_low_filt', -1))
         self.enc_dim = list(enc['dim'])
         self.enc_dropout = list(enc['dropout'])
         self.enc_layer_norm = list(enc['layer_norm'])
@@ -44,17 +46,23 @@ class ModelCfg(object):
         self.enc_sample_rate = list(enc['sample_rate'])
         self.enc_sample_style = enc['sample_style']
         self.bidirection = bool(enc['bidirection'])
-        assert enc['module'] == 'LSTM', 'oracle covers the LSTM encoder only'
+        self.enc_module = enc['module'].upper()
+        assert self.enc_module in ('LSTM', 'GRU'), 'oracle covers LSTM and GRU encoders'
+        self.emb_drop = float(model_cfg.get('emb_drop', 0.0))
         if self.enable_att:
             self.att_dim = int(att['dim'])
             self.att_temperature = float(att['temperature'])
             self.loc_kernel_size = int(att['loc_kernel_size'])
             self.loc_kernel_num = int(att['loc_kernel_num'])
-            assert att['mode'] == 'loc' and att['num_head'] == 1 and not att['v_proj']
+            self.att_mode = att['mode'].lower()
+            self.num_head = int(att['num_head'])
+            self.v_proj = bool(att['v_proj'])
+            assert self.att_mode in ('loc', 'dot')
             self.dec_dim = int(dec['dim'])
             self.dec_layer = int(dec['layer'])
             self.dec_dropout = float(dec['dropout'])
-            assert dec['module'] == 'LSTM'
+            self.dec_module = dec['module'].upper()
+            assert self.dec_module in ('LSTM', 'GRU')
 
     # --- shapes ---------------------------------------------------------------------------------
     def vgg_out_dim(self):
@@ -62,8 +70,11 @@ class ModelCfg(object):
             return self.input_size
         if self.vgg == 1:
             return (40 // 4) * 256
-        if self.vgg == 5:
+        if self.vgg in (3, 5):
             return (40 // 4) * 128
+        if self.vgg in (2, 4):
+            low, sf = self.vgg_low_filt, self.vgg_freq
+            return sf // 4 * (2 * low) + (40 - sf) // 4 * (128 - 2 * low)
         if self.vgg == 6:
             return self.input_size
         raise NotImplementedError('vgg=%d' % self.vgg)
@@ -102,15 +113,26 @@ def param_shapes(cfg):
                 s['encoder.layers.0.extractor.%d.layer_norm.bias' % (i + 1)] = (n,)
         d = cfg.vgg_out_dim()
         li = 1
+    elif cfg.vgg in (2, 3, 4):
+        c_in = cfg.input_size // 40
+        towers = [('extractor', 64, 128)] if cfg.vgg == 3 else \
+                 [('low_extractor', cfg.vgg_low_filt, 2 * cfg.vgg_low_filt), ('high_extractor', 64 - cfg.vgg_low_filt, 128 - 2 * cfg.vgg_low_filt)]
+        for tw, c1, c2 in towers:
+            for i, (ci, co) in zip([0, 2, 5, 7], [(c_in, c1), (c1, c1), (c1, c2), (c2, c2)]):
+                s['encoder.layers.0.%s.%d.weight' % (tw, i)] = (co, ci, 3, 3)
+                s['encoder.layers.0.%s.%d.bias' % (tw, i)] = (co,)
+        d = cfg.vgg_out_dim()
+        li = 1
     elif cfg.vgg == 6:
         li = 1
     for l, h in enumerate(cfg.enc_dim):
         pre = 'encoder.layers.%d.' % (li + l)
+        ng = 4 if cfg.enc_module == 'LSTM' else 3
         for sfx in ([''] + (['_reverse'] if cfg.bidirection else [])):
-            s[pre + 'layer.weight_ih_l0' + sfx] = (4 * h, d)
-            s[pre + 'layer.weight_hh_l0' + sfx] = (4 * h, h)
-            s[pre + 'layer.bias_ih_l0' + sfx] = (4 * h,)
-            s[pre + 'layer.bias_hh_l0' + sfx] = (4 * h,)
+            s[pre + 'layer.weight_ih_l0' + sfx] = (ng * h, d)
+            s[pre + 'layer.weight_hh_l0' + sfx] = (ng * h, h)
+            s[pre + 'layer.bias_ih_l0' + sfx] = (ng * h,)
+            s[pre + 'layer.bias_hh_l0' + sfx] = (ng * h,)
         out = (2 if cfg.bidirection else 1) * h
         if cfg.enc_layer_norm[l]:
             s[pre + 'ln.weight'] = (out,)
@@ -125,23 +147,32 @@ def param_shapes(cfg):
         s['ctc_layer.0.bias'] = (cfg.vocab_size,)
     if cfg.enable_att:
         s['pre_embed.weight'] = (cfg.vocab_size, cfg.dec_dim)
+        dg = 4 if cfg.dec_module == 'LSTM' else 3
         for l in range(cfg.dec_layer):
             din = enc_out + cfg.dec_dim if l == 0 else cfg.dec_dim
-            s['decoder.layers.weight_ih_l%d' % l] = (4 * cfg.dec_dim, din)
-            s['decoder.layers.weight_hh_l%d' % l] = (4 * cfg.dec_dim, cfg.dec_dim)
-            s['decoder.layers.bias_ih_l%d' % l] = (4 * cfg.dec_dim,)
-            s['decoder.layers.bias_hh_l%d' % l] = (4 * cfg.dec_dim,)
+            s['decoder.layers.weight_ih_l%d' % l] = (dg * cfg.dec_dim, din)
+            s['decoder.layers.weight_hh_l%d' % l] = (dg * cfg.dec_dim, cfg.dec_dim)
+            s['decoder.layers.bias_ih_l%d' % l] = (dg * cfg.dec_dim,)
+            s['decoder.layers.bias_hh_l%d' % l] = (dg * cfg.dec_dim,)
         s['decoder.char_trans.weight'] = (cfg.vocab_size, cfg.dec_dim)
         s['decoder.char_trans.bias'] = (cfg.vocab_size,)
         qd = cfg.dec_dim * cfg.dec_layer
-        s['attention.proj_q.weight'] = (cfg.att_dim, qd)
-        s['attention.proj_q.bias'] = (cfg.att_dim,)
-        s['attention.proj_k.weight'] = (cfg.att_dim, enc_out)
-        s['attention.proj_k.bias'] = (cfg.att_dim,)
-        s['attention.att_layer.loc_conv.weight'] = (cfg.loc_kernel_num, 1, 2 * cfg.loc_kernel_size + 1)
-        s['attention.att_layer.loc_proj.weight'] = (cfg.att_dim, cfg.loc_kernel_num)
-        s['attention.att_layer.gen_energy.weight'] = (1, cfg.att_dim)
-        s['attention.att_layer.gen_energy.bias'] = (1,)
+        nh = cfg.num_head
+        s['attention.proj_q.weight'] = (cfg.att_dim * nh, qd)
+        s['attention.proj_q.bias'] = (cfg.att_dim * nh,)
+        s['attention.proj_k.weight'] = (cfg.att_dim * nh, enc_out)
+        s['attention.proj_k.bias'] = (cfg.att_dim * nh,)
+        if cfg.v_proj:
+            s['attention.proj_v.weight'] = (enc_out * nh, enc_out)
+            s['attention.proj_v.bias'] = (enc_out * nh,)
+        if cfg.att_mode == 'loc':
+            s['attention.att_layer.loc_conv.weight'] = (cfg.loc_kernel_num, nh, 2 * cfg.loc_kernel_size + 1)
+            s['attention.att_layer.loc_proj.weight'] = (cfg.att_dim, cfg.loc_kernel_num)
+            s['attention.att_layer.gen_energy.weight'] = (1, cfg.att_dim)
+            s['attention.att_layer.gen_energy.bias'] = (1,)
+        if nh > 1:
+            s['attention.merge_head.weight'] = (enc_out, enc_out * nh)
+            s['attention.merge_head.bias'] = (enc_out,)
     return s
 
 
@@ -184,6 +215,33 @@ def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse, return_gates=False):
     return torch.stack(out, dim=1)
 
 
+def gru_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of nn.GRU(batch_first), zero initial state; gate order r,z,n; n = tanh(W_in x + b_in + r (W_hn h + b_hn))."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    xg = x @ w_ih.t() + b_ih
+    h = x.new_zeros(B, H)
+    out = [None] * T
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        hg = h @ w_hh.t() + b_hh
+        xr, xz, xn = xg[:, t].chunk(3, dim=-1)
+        hr, hz, hn = hg.chunk(3, dim=-1)
+        r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+        n = torch.tanh(xn + r * hn)
+        h = (1 - z) * n + z * h
+        out[t] = h
+    return torch.stack(out, dim=1)
+
+
+def bigru(x, P, pre, bidirection=True):
+    outs = [gru_direction(x, P[pre + 'weight_ih_l0'], P[pre + 'weight_hh_l0'], P[pre + 'bias_ih_l0'], P[pre + 'bias_hh_l0'], False)]
+    if bidirection:
+        outs.append(gru_direction(x, P[pre + 'weight_ih_l0_reverse'], P[pre + 'weight_hh_l0_reverse'],
+                                  P[pre + 'bias_ih_l0_reverse'], P[pre + 'bias_hh_l0_reverse'], True))
+    return torch.cat(outs, dim=-1)
+
+
 def bilstm(x, P, pre, bidirection=True):
     outs = [lstm_direction(x, P[pre + 'weight_ih_l0'], P[pre + 'weight_hh_l0'],
                            P[pre + 'bias_ih_l0'], P[pre + 'bias_hh_l0'], False)]
@@ -209,7 +267,7 @@ def bilstm_aten(x, P, pre, bidirection=True):
 
 def rnn_layer(x, x_len, P, pre, cfg, l, drop_mask=None, lstm_impl=bilstm):
     """RNNLayer.forward. drop_mask: None (eval) or a {0,1} float tensor of the LSTM output's shape."""
-    y = lstm_impl(x, P, pre + 'layer.', cfg.bidirection)
+    y = (bigru if cfg.enc_module == 'GRU' else lstm_impl)(x, P, pre + 'layer.', cfg.bidirection)
     if cfg.enc_layer_norm[l]:
         y = F.layer_norm(y, (y.shape[-1],), P[pre + 'ln.weight'], P[pre + 'ln.bias'])
     if drop_mask is not None:
@@ -265,12 +323,45 @@ def vgg_extractor(x, x_len, P, pre, layer_norm):
     return y, x_len
 
 
+def vgg_tower(y, P, pre, freq_only_second_pool):
+    """2 x (conv3x3 + ReLU) -> maxpool 2x2 -> 2 x (conv3x3 + ReLU) -> maxpool 2x2 or (1,2) (floor mode) on (B,C,T,F)."""
+    for i in (0, 2):
+        y = F.relu(F.conv2d(y, P[pre + '%d.weight' % i], P[pre + '%d.bias' % i], padding=1))
+    y = F.max_pool2d(y, 2, stride=2)
+    for i in (5, 7):
+        y = F.relu(F.conv2d(y, P[pre + '%d.weight' % i], P[pre + '%d.bias' % i], padding=1))
+    y = F.max_pool2d(y, (1, 2), stride=(1, 2)) if freq_only_second_pool else F.max_pool2d(y, 2, stride=2)
+    y = y.transpose(1, 2)
+    return y.contiguous().view(y.shape[0], y.shape[1], -1)
+
+
+def vgg_extractor_variants(x, x_len, P, pre, cfg):
+    """FreqVGGExtractor (vgg 2, src/module.py:746-841), VGGExtractor2 (vgg 3, :843-905), FreqVGGExtractor2 (vgg 4, :907-1001):
+    time is cropped to a multiple of 4 (vgg 2) or 2 (vgg 3, 4) and the length divided likewise."""
+    div = 4 if cfg.vgg == 2 else 2
+    x_len = x_len // div
+    if x.shape[1] % div != 0:
+        x = x[:, :-(x.shape[1] % div), :].contiguous()
+    B, T, _ = x.shape
+    y = x.view(B, T, x.shape[-1] // 40, 40).transpose(1, 2)
+    if cfg.vgg == 3:
+        return vgg_tower(y, P, pre + 'extractor.', True), x_len
+    sf = cfg.vgg_freq
+    lo = vgg_tower(y[:, :, :, :sf], P, pre + 'low_extractor.', cfg.vgg == 4)
+    hi = vgg_tower(y[:, :, :, sf:], P, pre + 'high_extractor.', cfg.vgg == 4)
+    return torch.cat((lo, hi), dim=-1), x_len
+
+
 def encoder(x, x_len, P, cfg, drop_masks=None, lstm_impl=bilstm, return_all=False):
     """Encoder.forward (src/asr.py:459-464). drop_masks: list (one per RNN layer) or None."""
     li = 0
     acts = []
     if cfg.vgg in (1, 5):
         x, x_len = vgg_extractor(x, x_len, P, 'encoder.layers.0.', cfg.vgg == 5)
+        li = 1
+        acts.append(x)
+    elif cfg.vgg in (2, 3, 4):
+        x, x_len = vgg_extractor_variants(x, x_len, P, 'encoder.layers.0.', cfg)
         li = 1
         acts.append(x)
     elif cfg.vgg == 6:
@@ -318,6 +409,86 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
     c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
     h = torch.sigmoid(o) * torch.tanh(c)
     return h, c
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    xr, xz, xn = (x @ w_ih.t() + b_ih).chunk(3, dim=-1)
+    hr, hz, hn = (h @ w_hh.t() + b_hh).chunk(3, dim=-1)
+    r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+    return (1 - z) * torch.tanh(xn + r * hn) + z * h
+
+
+def att_decoder_variants(enc, enc_len, P, cfg, decode_step, teacher=None, masks=None):
+    """The reference's step loop for every attention / decoder variant (src/asr.py:124-175, Attention.forward :331-364,
+    ScaleDotAttention / LocationAwareAttention src/module.py:1121-1189, Decoder.forward src/asr.py:262-270), teacher-forced
+    or greedy.  masks: None (eval) or a dict of {0,1} float tensors - 'emb' (B,L,dec_dim), 'layer' [t][l] (B,dec_dim) for the
+    inter-layer dropout of nn.LSTM / nn.GRU, 'final' [t] (B,dec_dim).  Returns logits (B,L,V), att (B,NH,L,T')."""
+    B, Tp, Dv = enc.shape
+    dim, nl, nh, ad = cfg.dec_dim, cfg.dec_layer, cfg.num_head, cfg.att_dim
+    lstm = cfg.dec_module == 'LSTM'
+    h = [enc.new_zeros(B, dim) for _ in range(nl)]
+    c = [enc.new_zeros(B, dim) for _ in range(nl)]
+    ar = torch.arange(Tp)[None, :]
+    mask = (ar >= enc_len[:, None])[:, None, :].expand(B, nh, Tp).reshape(B * nh, Tp)          # rows b * nh + head (:1107)
+    key = torch.tanh(enc @ P['attention.proj_k.weight'].t() + P['attention.proj_k.bias'])
+    value = torch.tanh(enc @ P['attention.proj_v.weight'].t() + P['attention.proj_v.bias']) if cfg.v_proj else enc
+    if nh > 1:
+        key = key.view(B, Tp, nh, ad).permute(0, 2, 1, 3).reshape(B * nh, Tp, ad)
+        if cfg.v_proj:
+            value = value.view(B, Tp, nh, Dv).permute(0, 2, 1, 3).reshape(B * nh, Tp, Dv)
+        else:
+            value = value.repeat(nh, 1, 1)          # head-major rows against batch-major keys: as the reference has it (:354)
+    prev_att = None
+    if cfg.att_mode == 'loc':
+        prev_att = torch.where(ar >= enc_len[:, None], torch.zeros(()), (1.0 / enc_len.float())[:, None].expand(B, Tp))
+        prev_att = prev_att[:, None, :].expand(B, nh, Tp)
+    E = P['pre_embed.weight']
+    last = E[torch.zeros(B, dtype=torch.long)]
+    temb = None
+    if teacher is not None:
+        temb = E[teacher]
+        if masks is not None and cfg.emb_drop > 0:
+            temb = temb * masks['emb'] / (1.0 - cfg.emb_drop)
+    logits_seq, att_seq = [], []
+    for t in range(decode_step):
+        q_in = torch.cat(h, dim=-1)
+        q = torch.tanh(q_in @ P['attention.proj_q.weight'].t() + P['attention.proj_q.bias']).view(B * nh, ad)
+        if cfg.att_mode == 'dot':
+            energy = torch.bmm(q.unsqueeze(1), key.transpose(1, 2)).squeeze(1)
+        else:
+            conv = F.conv1d(prev_att, P['attention.att_layer.loc_conv.weight'], padding=cfg.loc_kernel_size)
+            loc = torch.tanh(conv.transpose(1, 2) @ P['attention.att_layer.loc_proj.weight'].t())          # (B,T,ad)
+            loc = loc.unsqueeze(1).repeat(1, nh, 1, 1).view(B * nh, Tp, ad)
+            u = torch.tanh(key + q.unsqueeze(1) + loc)
+            energy = (u @ P['attention.att_layer.gen_energy.weight'].t()).squeeze(-1) + P['attention.att_layer.gen_energy.bias']
+        attn = torch.softmax((energy / cfg.att_temperature).masked_fill(mask, NEG_INF), dim=-1)
+        ctx = torch.bmm(attn.unsqueeze(1), value).squeeze(1)
+        attn = attn.view(B, nh, Tp)
+        if cfg.att_mode == 'loc':
+            prev_att = attn
+        if nh > 1:
+            ctx = ctx.view(B, nh * Dv) @ P['attention.merge_head.weight'].t() + P['attention.merge_head.bias']
+        x = torch.cat([last, ctx], dim=-1)
+        for l in range(nl):
+            W = [P['decoder.layers.%s_l%d' % (n, l)] for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            if lstm:
+                h[l], c[l] = lstm_cell(x, h[l], c[l], *W)
+            else:
+                h[l] = gru_cell(x, h[l], *W)
+            x = h[l]
+            if l + 1 < nl and masks is not None and cfg.dec_dropout > 0:
+                x = x * masks['layer'][t][l] / (1.0 - cfg.dec_dropout)
+        if masks is not None and cfg.dec_dropout > 0:
+            x = x * masks['final'][t] / (1.0 - cfg.dec_dropout)
+        logit = x @ P['decoder.char_trans.weight'].t() + P['decoder.char_trans.bias']
+        last = temb[:, t] if teacher is not None else E[logit.argmax(dim=-1)]
+        logits_seq.append(logit)
+        att_seq.append(attn)
+    return torch.stack(logits_seq, dim=1), torch.stack(att_seq, dim=2)
+
+
+def is_variant(cfg):
+    return (cfg.att_mode != 'loc' or cfg.num_head != 1 or cfg.v_proj or cfg.dec_module != 'LSTM' or cfg.dec_dropout > 0 or cfg.emb_drop > 0)
 
 
 def att_decoder(enc, enc_len, P, cfg, decode_step, teacher=None, state=None, return_state=False):
@@ -423,22 +594,25 @@ def seq_loss(att_logits, txt, label_smoothing):
     return F.cross_entropy(att_logits.reshape(b * t, v), txt.reshape(-1), ignore_index=0)
 
 
-def asr_forward(feat, feat_len, P, cfg, decode_step, teacher=None, drop_masks=None, lstm_impl=bilstm):
+def asr_forward(feat, feat_len, P, cfg, decode_step, teacher=None, drop_masks=None, lstm_impl=bilstm, dec_masks=None):
     """ASR.forward (src/asr.py:89-177) with tf_rate=1 (teacher given) or greedy decoding."""
     enc, enc_len = encoder(feat, feat_len, P, cfg, drop_masks, lstm_impl)
     ctc_out = ctc_head(enc, P) if cfg.enable_ctc else None
     att_out, att_seq = (None, None)
     if cfg.enable_att:
-        att_out, att_seq = att_decoder(enc, enc_len, P, cfg, decode_step, teacher)
+        if is_variant(cfg):
+            att_out, att_seq = att_decoder_variants(enc, enc_len, P, cfg, decode_step, teacher, dec_masks)
+        else:
+            att_out, att_seq = att_decoder(enc, enc_len, P, cfg, decode_step, teacher)
     return ctc_out, enc_len, att_out, att_seq
 
 
-def asr_losses(feat, feat_len, txt, P, cfg, label_smoothing=False, drop_masks=None, lstm_impl=bilstm):
+def asr_losses(feat, feat_len, txt, P, cfg, label_smoothing=False, drop_masks=None, lstm_impl=bilstm, dec_masks=None):
     """One training forward as the Solver wires it (bin/train_asr.py:204-248). Returns dict of tensors."""
     txt_len = (txt != 0).sum(dim=-1)
     L = int(txt_len.max())
     ctc_out, enc_len, att_out, att_seq = asr_forward(feat, feat_len, P, cfg, L, teacher=txt,
-                                                     drop_masks=drop_masks, lstm_impl=lstm_impl)
+                                                     drop_masks=drop_masks, lstm_impl=lstm_impl, dec_masks=dec_masks)
     res = {'enc_len': enc_len, 'ctc_output': ctc_out, 'att_output': att_out, 'att_seq': att_seq}
     total = 0.0
     if ctc_out is not None:

@@ -55,7 +55,20 @@ class MaskDrop(torch.nn.Module):
         return x * self.mask / (1.0 - self.p)
 
 
-def run_reference_model(model_cfg, D, V, seed, batch, label_smoothing=False, drop_masks=None, store_all=True):
+class MaskDropSeq(torch.nn.Module):
+    """A dropout module that is called once per decoder step: the t-th call applies the t-th mask."""
+
+    def __init__(self, masks, p):
+        super().__init__()
+        self.masks, self.p, self.t = masks, p, 0
+
+    def forward(self, x):
+        m = self.masks[self.t]
+        self.t += 1
+        return x * m / (1.0 - self.p)
+
+
+def run_reference_model(model_cfg, D, V, seed, batch, label_smoothing=False, drop_masks=None, store_all=True, dec_masks=None):
     from src.asr import ASR
     from src.util import LabelSmoothingLoss
     cfg = O.ModelCfg(model_cfg, D, V)
@@ -74,7 +87,14 @@ def run_reference_model(model_cfg, D, V, seed, batch, label_smoothing=False, dro
     feat, lens, txt = [torch.from_numpy(x) for x in batch]
     txt_len = (txt != 0).sum(-1)
     L = int(txt_len.max())
+    if dec_masks is not None:
+        # embedding dropout (src/asr.py:36,128) and the decoder's final dropout (src/asr.py:214,268) with KNOWN masks
+        model.embed_drop = MaskDrop(torch.from_numpy(dec_masks['emb']), cfg.emb_drop)
+        model.decoder.final_dropout = MaskDropSeq([torch.from_numpy(m) for m in dec_masks['final']], cfg.dec_dropout)
     ctc_out, enc_len, att_out, att_seq, _ = model(feat, lens, L, tf_rate=1.0, teacher=txt)
+    if dec_masks is not None:
+        model.embed_drop = torch.nn.Identity()
+        model.decoder.final_dropout = torch.nn.Identity()
     out = {'enc_len': enc_len.numpy()}
     total = 0
     if ctc_out is not None:
@@ -170,6 +190,50 @@ def gen_models():
     keep['att_seq_head'] = out['att_seq'][:, :, :4, :]
     save('g2_full_c2', {'model': mc, 'D': 160, 'V': V, 'wseed': 31, 'label_smoothing': False},
          dict(feat_seed=120, feat_len=batch[1], txt=batch[2], **keep))
+
+
+def gen_variants():
+    """G10: the model variants of SURVEY 8 row f-4 run by the genuine reference (eval mode; dropout through known masks)."""
+    V, D = 31, 20
+
+    def cfg_of(att=None, dec=None, enc_module='LSTM', emb_drop=0.0):
+        mc = small_model_cfg()
+        mc['encoder']['module'] = enc_module
+        mc['attention'].update(att or {})
+        mc['decoder'].update(dec or {})
+        if emb_drop:
+            mc['emb_drop'] = emb_drop
+        return mc
+    cases = [
+        ('g10_dot', cfg_of(att={'mode': 'dot'}), 71),
+        ('g10_loc_mh_vproj', cfg_of(att={'num_head': 2, 'v_proj': True}), 72),
+        ('g10_dot_mh', cfg_of(att={'mode': 'dot', 'num_head': 2}), 73),
+        ('g10_gru', cfg_of(dec={'module': 'GRU', 'layer': 2}, enc_module='GRU'), 74),
+    ]
+    for i, (name, mc, seed) in enumerate(cases):
+        batch = make_batch((160 + i) if name != 'g10_gru' else 101, 3, 37, D, 7, V)       # (batch 163 has an utterance CTC cannot align)
+        out = run_reference_model(mc, D, V, seed, batch)
+        assert np.isfinite(out['total_loss']), name
+        save(name, {'model': mc, 'D': D, 'V': V, 'wseed': seed, 'label_smoothing': False},
+             dict(feat=batch[0], feat_len=batch[1], txt=batch[2], **out))
+    # the other VGG front-ends: FreqVGGExtractor (vgg 2), VGGExtractor2 (vgg 3), FreqVGGExtractor2 (vgg 4)
+    for vgg in (2, 3, 4):
+        mc = small_model_cfg(vgg=vgg, dims=(16,), rates=(1,))
+        mc['encoder'].update({'vgg_freq': 12, 'vgg_low_filt': 4})
+        batch = make_batch(180 + vgg, 2, 43, 80, 4, V)
+        out = run_reference_model(mc, 80, V, 80 + vgg, batch, store_all=False)
+        save('g10_vgg%d' % vgg, {'model': mc, 'D': 80, 'V': V, 'wseed': 80 + vgg, 'label_smoothing': False},
+             dict(feat=batch[0], feat_len=batch[1], txt=batch[2], **out))
+    # decoder dropout + embedding dropout with known masks (one decoder layer: nn.LSTM's own inter-layer dropout cannot be pinned)
+    mc = cfg_of(dec={'dropout': 0.25}, emb_drop=0.2)
+    batch = make_batch(170, 3, 37, D, 7, V)
+    L = int((batch[2] != 0).sum(-1).max())
+    g = np.random.Generator(np.random.PCG64(77))
+    dm = {'emb': (g.random((3, batch[2].shape[1], 12)) >= 0.2).astype(np.float32),
+          'final': [(g.random((3, 12)) >= 0.25).astype(np.float32) for _ in range(L)]}
+    out = run_reference_model(mc, D, V, 75, batch, dec_masks=dm)
+    save('g10_decdrop', {'model': mc, 'D': D, 'V': V, 'wseed': 75, 'label_smoothing': False},
+         dict(feat=batch[0], feat_len=batch[1], txt=batch[2], mask_emb=dm['emb'], mask_final=np.stack(dm['final'], 0), **out))
 
 
 def gen_ctc():
@@ -393,11 +457,13 @@ def gen_ckpt():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['models', 'ctc', 'decode', 'decode4', 'frontend', 'ckpt']
+    which = sys.argv[1:] or ['models', 'variants', 'ctc', 'decode', 'decode4', 'frontend', 'ckpt']
     if 'ckpt' in which:
         gen_ckpt()
     if 'models' in which:
         gen_models()
+    if 'variants' in which:
+        gen_variants()
     if 'ctc' in which:
         gen_ctc()
     if 'decode' in which:

@@ -176,9 +176,10 @@ def test_full_size_librispeech_config(golden_dir, prec):
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
-@pytest.mark.parametrize('name', ['g3_small_vgg1', 'g3_small_vgg5'])
+@pytest.mark.parametrize('name', ['g3_small_vgg1', 'g3_small_vgg5', 'g10_vgg2', 'g10_vgg3', 'g10_vgg4'])
 def test_vgg_front_ends_vs_reference_fixtures(golden_dir, name, prec):
-    """VGGExtractor (vgg 1) and VGGExtractor_LN (vgg 5): outputs, losses, per-parameter gradient norms + heads."""
+    """VGGExtractor (vgg 1), VGGExtractor_LN (vgg 5), FreqVGGExtractor (vgg 2), VGGExtractor2 (vgg 3), FreqVGGExtractor2 (vgg 4;
+    reference src/module.py:582-1001): outputs, losses, per-parameter gradient norms + heads."""
     meta, z = load(golden_dir, name)
     cfg, sd, model = build(meta, prec)
     model.eval()
@@ -199,7 +200,10 @@ def test_vgg_front_ends_vs_reference_fixtures(golden_dir, name, prec):
     for k, p in model.named_parameters():
         r = float(z['gradnorm.' + k])
         n = float(p.grad.norm())
-        tol = (5e-4 if f32 else 6e-2) * r + 1e-5 * gmax
+        # bf16 contraction mode: 6 % on the norm; the 4- and 8-channel low band of the frequency-split extractors sums so few
+        # products per gradient element that the operand rounding does not average out (measured 10 %): 15 % there
+        rel = 5e-4 if f32 else (0.15 if 'low_extractor' in k else 6e-2)
+        tol = rel * r + 1e-5 * gmax
         report.append(('gradnorm.' + k, abs(n - r), tol, abs(n - r) <= tol))
         if f32:
             err = float(np.abs(p.grad.reshape(-1)[:8].cpu().numpy() - z['gradhead.' + k]).max())

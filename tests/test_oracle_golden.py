@@ -18,12 +18,12 @@ def load(golden_dir, name):
     return meta, z
 
 
-def run_oracle(meta, z, feat=None, drop_masks=None, lstm_impl=O.bilstm):
+def run_oracle(meta, z, feat=None, drop_masks=None, lstm_impl=O.bilstm, dec_masks=None):
     cfg = O.ModelCfg(meta['model'], meta['D'], meta['V'])
     P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_state_dict(O.param_shapes(cfg), meta['wseed']).items()}
     feat = torch.from_numpy(z['feat']) if feat is None else feat
     res = O.asr_losses(feat, torch.from_numpy(z['feat_len']), torch.from_numpy(z['txt']), P, cfg,
-                       label_smoothing=meta['label_smoothing'], drop_masks=drop_masks, lstm_impl=lstm_impl)
+                       label_smoothing=meta['label_smoothing'], drop_masks=drop_masks, lstm_impl=lstm_impl, dec_masks=dec_masks)
     res['total_loss'].backward()
     return cfg, P, res
 
@@ -54,7 +54,33 @@ def test_small_models_match_reference(golden_dir, name, impl):
     assert abs(total - float(z['grad_norm'])) < 1e-4 * max(1.0, total)
 
 
-@pytest.mark.parametrize('name', ['g3_small_vgg1', 'g3_small_vgg5'])
+VARIANTS = ['g10_dot', 'g10_loc_mh_vproj', 'g10_dot_mh', 'g10_gru', 'g10_decdrop']
+
+
+def variant_masks(z):
+    if 'mask_emb' not in z.files:
+        return None
+    return {'emb': torch.from_numpy(z['mask_emb']), 'final': [torch.from_numpy(m) for m in z['mask_final']], 'layer': None}
+
+
+@pytest.mark.parametrize('name', VARIANTS)
+def test_variant_models_match_reference(golden_dir, name):
+    """scaled-dot / multi-head / value-projected attention, GRU encoder + 2-layer GRU decoder, decoder and
+    embedding dropout with known masks - the oracle's restatement against the genuine reference's outputs and gradients."""
+    meta, z = load(golden_dir, name)
+    cfg, P, res = run_oracle(meta, z, dec_masks=variant_masks(z))
+    assert np.array_equal(res['enc_len'].numpy(), z['enc_len'])
+    for key in ('ctc_output', 'att_output', 'att_seq'):
+        np.testing.assert_allclose(res[key].detach().numpy(), z[key], atol=2e-5, rtol=1e-5, err_msg=key)
+    for key in ('ctc_loss', 'att_loss', 'total_loss'):
+        assert abs(float(res[key].detach()) - float(z[key])) < 1e-5 * max(1.0, abs(float(z[key])))
+    for k, p in P.items():
+        g = p.grad.numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+        ref = z['grad.' + k]
+        np.testing.assert_allclose(g, ref, atol=3e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['g3_small_vgg1', 'g3_small_vgg5', 'g10_vgg2', 'g10_vgg3', 'g10_vgg4'])
 def test_vgg_models_match_reference(golden_dir, name):
     meta, z = load(golden_dir, name)
     cfg, P, res = run_oracle(meta, z)

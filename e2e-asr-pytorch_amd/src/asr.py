@@ -62,11 +62,14 @@ class Encoder(nn.Module):
                 ext = VGGExtractor_LN(input_size)
             elif vgg == 6:
                 ext = Downsampler(input_size)
+            elif vgg == 7:
+                from src.module import Featemb_Extractor
+                ext = Featemb_Extractor(input_size)
             else:
                 raise NotImplementedError('vgg = {} is not available on the HIP path'.format(vgg))
             layers.append(ext)
             input_dim = ext.out_dim
-            self.sample_rate = self.sample_rate * (4 if (vgg < 3 or vgg == 6) else 2)
+            self.sample_rate = 1 if vgg == 7 else self.sample_rate * (4 if (vgg < 3 or vgg == 6) else 2)
         if module not in ('LSTM', 'GRU'):
             raise NotImplementedError('encoder module %s is not available on the HIP path' % module)
         for l in range(len(dim)):

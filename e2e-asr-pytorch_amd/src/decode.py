@@ -63,6 +63,9 @@ class BeamDecoder(nn.Module):
         assert emb_decoder is None, 'embedding-fusion decoding is outside the HIP path'
         self.beam_size, self.min_len_ratio, self.max_len_ratio, self.asr = beam_size, min_len_ratio, max_len_ratio, asr
         assert self.asr.enable_att
+        if not (self.asr.decoder.fast and self.asr.attention.fast):
+            raise NotImplementedError('beam search runs on the decode kernels of the shipped decoder (LSTM, location-aware attention, '
+                                      'one head); the model variants of src/variants.py train and validate greedily only')
         self.apply_ctc = ctc_weight > 0
         if self.apply_ctc:
             assert self.asr.ctc_weight > 0, 'ASR was not trained with CTC decoder'

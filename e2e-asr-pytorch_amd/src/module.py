@@ -114,6 +114,20 @@ class Downsampler(nn.Module):
         return out, feat_len // self.sample_rate
 
 
+class Featemb_Extractor(nn.Module):
+    """vgg: 7 - one Linear(input, 256) in front of the recurrent layers (reference src/module.py:732-742,
+    config/librispeech_asr_upstream.yaml)."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.emb_dim = self.out_dim = 256
+        self.dense = nn.Linear(input_dim, self.emb_dim)
+
+    def forward(self, feature, feat_len, ctx=None):
+        from src.variants import LinearActFn
+        return LinearActFn.apply(ctx.anchor, feature, self.dense.weight, self.dense.bias, H.ACT_NONE, ctx.prec), feat_len
+
+
 class LocationAwareAttention(nn.Module):
     """Parameter container of the location-aware attention (reference src/module.py:1135-1173)."""
 

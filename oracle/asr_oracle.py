@@ -77,6 +77,8 @@ class ModelCfg(object):
             return sf // 4 * (2 * low) + (40 - sf) // 4 * (128 - 2 * low)
         if self.vgg == 6:
             return self.input_size
+        if self.vgg == 7:
+            return 256
         raise NotImplementedError('vgg=%d' % self.vgg)
 
     def enc_out_dim(self):
@@ -124,6 +126,11 @@ def param_shapes(cfg):
         d = cfg.vgg_out_dim()
         li = 1
     elif cfg.vgg == 6:
+        li = 1
+    elif cfg.vgg == 7:                       # Featemb_Extractor: one Linear(input, 256), src/module.py:732-742
+        s['encoder.layers.0.dense.weight'] = (256, cfg.input_size)
+        s['encoder.layers.0.dense.bias'] = (256,)
+        d = 256
         li = 1
     for l, h in enumerate(cfg.enc_dim):
         pre = 'encoder.layers.%d.' % (li + l)
@@ -362,6 +369,10 @@ def encoder(x, x_len, P, cfg, drop_masks=None, lstm_impl=bilstm, return_all=Fals
         acts.append(x)
     elif cfg.vgg in (2, 3, 4):
         x, x_len = vgg_extractor_variants(x, x_len, P, 'encoder.layers.0.', cfg)
+        li = 1
+        acts.append(x)
+    elif cfg.vgg == 7:
+        x = x @ P['encoder.layers.0.dense.weight'].t() + P['encoder.layers.0.dense.bias']
         li = 1
         acts.append(x)
     elif cfg.vgg == 6:

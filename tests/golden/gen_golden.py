@@ -224,6 +224,12 @@ def gen_variants():
         out = run_reference_model(mc, 80, V, 80 + vgg, batch, store_all=False)
         save('g10_vgg%d' % vgg, {'model': mc, 'D': 80, 'V': V, 'wseed': 80 + vgg, 'label_smoothing': False},
              dict(feat=batch[0], feat_len=batch[1], txt=batch[2], **out))
+    # Featemb_Extractor (vgg 7, config/librispeech_asr_upstream.yaml: CTC only)
+    mc = small_model_cfg(vgg=7, ctc_weight=1.0, dims=(16,), rates=(1,))
+    batch = make_batch(101, 3, 37, D, 7, V)
+    out = run_reference_model(mc, D, V, 87, batch)
+    save('g10_vgg7', {'model': mc, 'D': D, 'V': V, 'wseed': 87, 'label_smoothing': False},
+         dict(feat=batch[0], feat_len=batch[1], txt=batch[2], **out))
     # decoder dropout + embedding dropout with known masks (one decoder layer: nn.LSTM's own inter-layer dropout cannot be pinned)
     mc = cfg_of(dec={'dropout': 0.25}, emb_drop=0.2)
     batch = make_batch(170, 3, 37, D, 7, V)

@@ -54,7 +54,7 @@ def test_small_models_match_reference(golden_dir, name, impl):
     assert abs(total - float(z['grad_norm'])) < 1e-4 * max(1.0, total)
 
 
-VARIANTS = ['g10_dot', 'g10_loc_mh_vproj', 'g10_dot_mh', 'g10_gru', 'g10_decdrop']
+VARIANTS = ['g10_dot', 'g10_loc_mh_vproj', 'g10_dot_mh', 'g10_gru', 'g10_decdrop', 'g10_vgg7']
 
 
 def variant_masks(z):
@@ -71,9 +71,11 @@ def test_variant_models_match_reference(golden_dir, name):
     cfg, P, res = run_oracle(meta, z, dec_masks=variant_masks(z))
     assert np.array_equal(res['enc_len'].numpy(), z['enc_len'])
     for key in ('ctc_output', 'att_output', 'att_seq'):
-        np.testing.assert_allclose(res[key].detach().numpy(), z[key], atol=2e-5, rtol=1e-5, err_msg=key)
+        if key in z.files:
+            np.testing.assert_allclose(res[key].detach().numpy(), z[key], atol=2e-5, rtol=1e-5, err_msg=key)
     for key in ('ctc_loss', 'att_loss', 'total_loss'):
-        assert abs(float(res[key].detach()) - float(z[key])) < 1e-5 * max(1.0, abs(float(z[key])))
+        if key in z.files:
+            assert abs(float(res[key].detach()) - float(z[key])) < 1e-5 * max(1.0, abs(float(z[key])))
     for k, p in P.items():
         g = p.grad.numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
         ref = z['grad.' + k]

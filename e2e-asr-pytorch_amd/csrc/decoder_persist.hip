@@ -561,6 +561,7 @@ PersistPlan persist_plan(const asr_dec_dims_t& d) {
     fl += 2 * pl.KCP + 2 * ((d.A + 3) & ~3) + ((pl.NT * pl.TE + 2 * d.Ks + 8 + 3) & ~3) +
           (size_t)NCW * epl + ((4 * pl.UPW + 3) & ~3) + (size_t)pl.NT * 2 * pl.SG2;
     pl.lds = 2 * (size_t)(((pl.TE * d.A + 7) & ~7) + ((pl.TE * d.E + 7) & ~7) + epl * FCVX_LD + conv_img_shorts(conv_geo(epl, d.Ks))) + 4 * fl;
+    if (getenv("ASR_DEC_PLAN_DEBUG")) fprintf(stderr, "[asr] resident fwd plan B=%d T'=%d: NT=%d TE=%d UPW=%d LDS=%zu\n", d.B, d.Tp, pl.NT, pl.TE, pl.UPW, pl.lds);
     if (pl.lds > 156 * 1024) return pl;
     pl.status_bytes = 4096;
     pl.xbuf_bytes = align_up256(2 * (size_t)d.B * pl.NT * (pl.HG2 + pl.QG2 + pl.SG2) * sizeof(u64));
@@ -1114,6 +1115,7 @@ PersistPlanB persist_plan_b(const asr_dec_dims_t& d) {
             if (pl.NT * pl.QG2 * 2 < NPB * 64 * 11) continue;       // s_qst doubles as the stage of the polling waves' partial accumulators
             const BCarve cv = bwd_carve(TE, 12, d.A, d.E, d.Kn, d.Ks, pl.NT, pl.UPW, pl.CG2, pl.QG2, pl.NG2);
             pl.lds = 2 * (size_t)cv.shorts + 4 * (size_t)cv.floats;
+            if (getenv("ASR_DEC_PLAN_DEBUG")) fprintf(stderr, "[asr] resident bwd plan B=%d T'=%d: NT=%d TE=%d LDS=%zu\n", d.B, d.Tp, pl.NT, pl.TE, pl.lds);
             if (pl.lds > 160 * 1024 - 4096) continue;
             found = true;
         }

@@ -3,7 +3,7 @@
 The jitter build sleeps for a pseudo-random time at every phase boundary of every wave; each launch (new epoch) runs under a
 different interleaving.  The same decoder forward (+ backward) is launched N times and compared with the launch-per-step
 kernels; anything beyond bf16 rounding that CHANGES from launch to launch is an ordering bug.
-usage: python tools/jitter_dec.py [N] [small|bench|both]"""
+usage: python tools/jitter_dec.py [N] [small|bench|both|stream]      (stream: the streamed-tile plans, forced, at B=8 x T'=1225 and B=64 x T'=1500)"""
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'e2e-asr-pytorch_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -21,7 +21,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 which = sys.argv[2] if len(sys.argv) > 2 else 'both'
 
 
-def run(model, B, Tp, L, E, tag):
+def run(model, B, Tp, L, E, tag, pflags=3):
     g = torch.Generator().manual_seed(3)
     enc0 = torch.tanh(torch.randn(B, Tp, E, generator=g)).cuda()
     enc_len = torch.randint(max(Tp // 2, 1), Tp + 1, (B,), generator=g); enc_len[0] = Tp; enc_len = enc_len.cuda()
@@ -40,12 +40,12 @@ def run(model, B, Tp, L, E, tag):
         gr = torch.cat([p.grad.detach().reshape(-1) for n, p in model.named_parameters() if n in names] + [enc.grad.reshape(-1)])
         return logits.detach().clone(), att.detach().clone(), gr.clone()
     ref = one(0)
-    first = one(3)
+    first = one(pflags)
     base = [float((first[0] - ref[0]).abs().max()), float((first[1] - ref[1]).abs().max()), float((first[2] - ref[2]).norm() / ref[2].norm())]
     print('%s: persistent vs per-step kernels: logits %.2e  att %.2e  grad rel %.2e' % (tag, *base))
     worst = [0.0, 0.0, 0.0]
     for it in range(N):
-        cur = one(3)
+        cur = one(pflags)
         d = [float((cur[0] - first[0]).abs().max()), float((cur[1] - first[1]).abs().max()), float((cur[2] - first[2]).norm() / first[2].norm())]
         worst = [max(a, b) for a, b in zip(worst, d)]
         if d[0] > 1e-6 or d[1] > 1e-6 or d[2] > 1e-4:
@@ -65,3 +65,8 @@ if which in ('bench', 'both'):
     config = yaml.safe_load(open(os.path.join(ROOT, 'e2e-asr-pytorch_amd', 'config', 'librispeech_asr.yaml')))
     model = ASR(160, 31, 16, prec='bf16', seed=5, **config['model']).cuda().train()
     run(model, 16, 600, 60, 640, 'bench shape (B=16, T\'=600, L=60)')
+if which == 'stream':
+    config = yaml.safe_load(open(os.path.join(ROOT, 'e2e-asr-pytorch_amd', 'config', 'librispeech_asr.yaml')))
+    model = ASR(160, 31, 16, prec='bf16', seed=5, **config['model']).cuda().train()
+    run(model, 8, 1225, 24, 640, "streamed plans (B=8, T'=1225, L=24)", pflags=3 | 4 | 8)
+    run(model, 64, 1500, 8, 640, "streamed plans (B=64, T'=1500, L=8)", pflags=3 | 4 | 8)

@@ -154,3 +154,29 @@ def test_config4_size_beam_search_matches_reference(golden_dir):
     for u in range(nutt):
         check(batched[u], u, 'batched')
         check(dec(feats[u:u + 1, :lens[u]].cuda(), torch.tensor(lens[u:u + 1]).cuda()), u, 'single')
+
+
+@pytest.mark.parametrize('seed,T,beam,ctc_w,lm_w', [(301, 47, 3, 0.4, 0.0), (302, 83, 5, 0.3, 0.6), (303, 29, 2, 0.0, 0.4), (304, 120, 6, 0.5, 0.2)])
+def test_beam_search_matches_decode_oracle_on_new_inputs(g7, seed, T, beam, ctc_w, lm_w):
+    """Seeded utterances that are NOT in the fixtures, other beam widths and fusion weights: the HIP decoder against the CPU
+    restatement of src/decode.py / src/ctc.py / src/lm.py (oracle/decode_oracle.py, itself pinned to the reference's hypotheses by
+    tests/test_oracle_golden.py::test_decode_*).  Token sequences must be identical; scores within fp32 accumulation noise."""
+    from oracle import decode_oracle as D
+    meta, _ = g7
+    dec = _decoder(meta, ctc_w, lm_w, beam=beam)
+    dec.max_len_ratio = 0.15
+    g = np.random.Generator(np.random.PCG64(seed))
+    feat = torch.from_numpy(g.random((1, T, meta['D']), dtype=np.float32))
+    flen = torch.tensor([T], dtype=torch.int64)
+    hyps = dec(feat.cuda(), flen.cuda())
+    cfg = O.ModelCfg(meta['model'], meta['D'], meta['V'])
+    P = O.seeded_state_dict(O.param_shapes(cfg), meta['wseed'])
+    lm = None
+    if lm_w > 0:
+        P_lm = {k: v.detach().cpu() for k, v in dec.lm.state_dict().items()}
+        lm = (P_lm, meta['lm'])
+    ref = D.beam_search(feat, flen, P, cfg, beam, meta['min_len_ratio'], 0.15, ctc_weight=ctc_w, lm=lm, lm_weight=lm_w)
+    assert len(hyps) == len(ref)
+    for i, (h, (seq, scores)) in enumerate(zip(hyps, ref)):
+        assert h.outIndex == seq, (i, h.outIndex, seq)
+        np.testing.assert_allclose(np.array(h.output_scores, dtype=np.float32), np.array(scores, np.float32), rtol=1e-4, atol=2e-3)

@@ -162,3 +162,61 @@ def test_lstm_loop_equals_aten():
         'weight_ih_l0_reverse': (12, 5), 'weight_hh_l0_reverse': (12, 3), 'bias_ih_l0_reverse': (12,),
         'bias_hh_l0_reverse': (12,)}.items()}
     np.testing.assert_allclose(O.bilstm(x, P, '').numpy(), O.bilstm_aten(x, P, '').numpy(), atol=1e-6)
+
+
+# ---- inference leg: oracle/decode_oracle.py against the reference's hypotheses (src/ctc.py, src/decode.py, src/lm.py) ----
+def _decode_setup(meta, wseed_key='wseed'):
+    from oracle import decode_oracle as D
+    cfg = O.ModelCfg(meta['model'], meta['D'], meta['V'])
+    P = O.seeded_state_dict(O.param_shapes(cfg), meta[wseed_key])
+    lm_cfg = meta['lm']
+    shapes = {'emb.weight': (meta['V'], lm_cfg['emb_dim'])}
+    for l in range(lm_cfg['n_layers']):
+        din = lm_cfg['emb_dim'] if l == 0 else lm_cfg['dim']
+        shapes['rnn.weight_ih_l%d' % l] = (4 * lm_cfg['dim'], din)
+        shapes['rnn.weight_hh_l%d' % l] = (4 * lm_cfg['dim'], lm_cfg['dim'])
+        shapes['rnn.bias_ih_l%d' % l] = (4 * lm_cfg['dim'],)
+        shapes['rnn.bias_hh_l%d' % l] = (4 * lm_cfg['dim'],)
+    if not lm_cfg['emb_tying']:
+        shapes['trans.weight'] = (meta['V'], lm_cfg['emb_dim'])
+        shapes['trans.bias'] = (meta['V'],)
+    P_lm = O.seeded_state_dict(shapes, meta['lm_wseed'])
+    return D, cfg, P, (P_lm, lm_cfg)
+
+
+def test_decode_prefix_scorer_matches_reference(golden_dir):
+    from oracle import decode_oracle as D
+    meta, z = load(golden_dir, 'g7_decode')
+    x = z['ctc_logp']
+    cand = z['cand'].tolist()
+    r0 = D.ctc_prefix_init(x)
+    np.testing.assert_array_equal(r0, z['r0'])
+    psi1, r1 = D.ctc_prefix_cheap(x, [], r0, cand)
+    psi2, r2 = D.ctc_prefix_cheap(x, [7], r1[cand.index(7)], cand)
+    psi3, r3 = D.ctc_prefix_cheap(x, [7, 7], r2[cand.index(7)], [7, 1, 3])
+    for got, key in ((psi1, 'psi1'), (r1, 'r1'), (psi2, 'psi2'), (r2, 'r2'), (psi3, 'psi3'), (r3, 'r3')):
+        np.testing.assert_array_equal(got, z[key], err_msg=key)          # same float32 numpy arithmetic: bit-exact
+
+
+@pytest.mark.parametrize('tag,ctc_w,lm_w', [('att', 0.0, 0.0), ('ctc', 0.3, 0.0), ('ctc_lm', 0.3, 0.5)])
+def test_decode_beam_search_matches_reference(golden_dir, tag, ctc_w, lm_w):
+    meta, z = load(golden_dir, 'g7_decode')
+    D, cfg, P, lm = _decode_setup(meta)
+    hyps = D.beam_search(torch.from_numpy(z['feat']), torch.from_numpy(z['feat_len']), P, cfg, meta['beam'], meta['min_len_ratio'],
+                         meta['max_len_ratio'], ctc_weight=ctc_w, lm=lm if lm_w > 0 else None, lm_weight=lm_w)
+    assert len(hyps) == int(z['n_' + tag])
+    for i, (seq, scores) in enumerate(hyps):
+        assert seq == z['%s_seq%d' % (tag, i)].tolist(), (tag, i)
+        np.testing.assert_allclose(np.array(scores, np.float32), z['%s_score%d' % (tag, i)], atol=2e-4, err_msg='%s %d' % (tag, i))
+
+
+def test_decode_config4_size_matches_reference(golden_dir):
+    """BASELINE config 4 at its size: 12 M-parameter model, beam 8, CTC 0.3, 4 x 1024 LM 0.3 (first utterance, T = 400)."""
+    meta, z = load(golden_dir, 'g7b_decode_config4')
+    D, cfg, P, lm = _decode_setup(meta)
+    hyps = D.beam_search(torch.from_numpy(z['feat0']), torch.from_numpy(z['feat_len0']), P, cfg, meta['beam'], meta['min_len_ratio'],
+                         meta['max_len_ratio'], ctc_weight=meta['ctc_weight'], lm=lm, lm_weight=meta['lm_weight'])
+    assert len(hyps) == int(z['n0'])
+    for i, (seq, scores) in enumerate(hyps):
+        assert seq == z['u0_seq%d' % i].tolist(), i
+        np.testing.assert_allclose(np.array(scores, np.float32), z['u0_score%d' % i], atol=5e-4)

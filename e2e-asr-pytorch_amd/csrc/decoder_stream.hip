@@ -244,11 +244,11 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                 acc0 = wave_sum_dpp(acc0); acc1 = wave_sum_dpp(acc1);
             }
             if (lane == 0) {
-                const float q0 = tanhf(acc0 + b0), q1 = tanhf(acc1 + b1);
+                const float q0 = tanh_f(acc0 + b0), q1 = tanh_f(acc1 + b1);
+                u64* dst = out + (long)NT * p.HG2 + (long)j * p.QG2 + (o0 >> 1);
+                if (local) publish<true>(dst, pack2(q0, q1, want)); else publish<false>(dst, pack2(q0, q1, want));     // the hop first
                 if (q_base + o0 < A) p.s.q[row * A + q_base + o0] = q0;
                 if (o0 + 1 < p.QPW && q_base + o0 + 1 < A) p.s.q[row * A + q_base + o0 + 1] = q1;
-                u64* dst = out + (long)NT * p.HG2 + (long)j * p.QG2 + (o0 >> 1);
-                if (local) publish<true>(dst, pack2(q0, q1, want)); else publish<false>(dst, pack2(q0, q1, want));
             }
         }
         if (tz == 0 && (p.QPW + 1) / 2 < p.QG2) {                       // pad granule of an odd record length
@@ -529,20 +529,25 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
             const int ul = tz, unit = u_base + ul;
             const bool uok = ul < p.UPW && unit < Dd;
             float hv = 0.f;
+            // the hop starts at the publish: the activations use the fast exp / rcp forms (1 - 2 ulp) and the granule leaves
+            // BEFORE the six stores of the step's saved state (one in-order vector-memory queue per wave)
+            float ai = 0.f, af = 0.f, ag = 0.f, ao = 0.f;
             if (uok) {
-                const float ai = sigmoidf_(s_g[ul]), af = sigmoidf_(s_g[p.UPW + ul]);
-                const float ag = tanhf(s_g[2 * p.UPW + ul]), ao = sigmoidf_(s_g[3 * p.UPW + ul]);
+                ai = sigm_f(s_g[ul]); af = sigm_f(s_g[p.UPW + ul]);
+                ag = tanh_f(s_g[2 * p.UPW + ul]); ao = sigm_f(s_g[3 * p.UPW + ul]);
                 c_state = af * c_state + ai * ag;
-                hv = ao * tanhf(c_state);
-                float* go = p.s.gates + row * 4 * Dd;
-                go[unit] = ai; go[Dd + unit] = af; go[2 * Dd + unit] = ag; go[3 * Dd + unit] = ao;
-                p.s.cs[row * Dd + unit] = c_state;
-                p.s.hs[row * Dd + unit] = hv;
+                hv = ao * tanh_f(c_state);
             }
             const float hn = __shfl_down(hv, 1);                        // pairs never straddle a wave (64 is even)
             if (t + 1 < L && (ul & 1) == 0 && ul < 2 * p.HG2) {
                 u64* dst = out + (long)j * p.HG2 + (ul >> 1);
                 if (local) publish<true>(dst, pack2(hv, hn, want)); else publish<false>(dst, pack2(hv, hn, want));
+            }
+            if (uok) {
+                float* go = p.s.gates + row * 4 * Dd;
+                go[unit] = ai; go[Dd + unit] = af; go[2 * Dd + unit] = ag; go[3 * Dd + unit] = ao;
+                p.s.cs[row * Dd + unit] = c_state;
+                p.s.hs[row * Dd + unit] = hv;
             }
         }
     }

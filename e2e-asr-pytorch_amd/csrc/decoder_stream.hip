@@ -748,8 +748,8 @@ __host__ __device__ inline SBCarve sbwd_carve(int TEB, int A, int E, int Kn, int
 // contribution of a (unit, 16-frame tile) is added to the value read ahead (`old`) and stored at once, and the tile's key
 // fragment is re-requested for the NEXT group as soon as it has been consumed - neither lives longer than it must
 template <int NU>
-__device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU], float (&dq)[NU], const float4 (&old)[NU][SW_MT], uint2 (&kf)[NU][SW_MT],
-                                            float* dk_g, const unsigned short* key_next, const int (&acol)[NU], int A, int MTB_left_next,
+__device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU], float (&dq)[NU], float4 (&old)[NU][SW_MT], uint2 (&kf)[NU][SW_MT],
+                                            float* dk_g, const float* dk_next, const unsigned short* key_next, const int (&acol)[NU], int A, int MTB_left_next,
                                             int nu_cnt, int wave, int nw, int MTg, int AP, const unsigned short* s_cvx, const unsigned short* s_cvT,
                                             const float* s_de, unsigned short* s_dl, int lane) {
     int opaque = 0;
@@ -784,9 +784,12 @@ __device__ __forceinline__ void sweep_group(Sweep<NU>& S, const float (&qa)[NU],
                         du4[r] = du;
                         dl[r] = (__bf16)(du * (1.f - loc * loc));
                     }
-                    if (a < A) {
+                    {
                         const float4 o = old[nu][mt];
-                        *reinterpret_cast<float4*>(dk_g + ((long)4 * mt * A + acol[nu]) * 4) = make_float4(o.x + du4[0], o.y + du4[1], o.z + du4[2], o.w + du4[3]);
+                        if (a < A) *reinterpret_cast<float4*>(dk_g + ((long)4 * mt * A + acol[nu]) * 4) = make_float4(o.x + du4[0], o.y + du4[1], o.z + du4[2], o.w + du4[3]);
+                        // the register is free: the NEXT group's value of this (unit, tile) is requested into it (one group of
+                        // look-ahead at no extra registers; a second array for it cost 36 registers and spilled)
+                        if (dk_next) old[nu][mt] = *reinterpret_cast<const float4*>(dk_next + ((long)4 * min(mt, MTB_left_next - 1) * A + acol[nu]) * 4);
                     }
                     const s16x4_ dls = __builtin_bit_cast(s16x4_, dl);
 #pragma unroll
@@ -828,32 +831,20 @@ __device__ __forceinline__ void sweep_tile(const PSB& p, Sweep<NU>& S, const flo
     const int GF = 16 * SW_MT;
     const int cvk0 = min(cvi0, Kn * GF - 1) / GF, cvf0 = min(cvi0, Kn * GF - 1) - cvk0 * GF;
     const int cvk1 = min(cvi1, Kn * GF - 1) / GF, cvf1 = min(cvi1, Kn * GF - 1) - cvk1 * GF;
-    float4 oldn[NU][SW_MT];
+    // dkey of the group's elements.  DKPF (weight rows streamed, registers to spare): read ahead - the first group's here, every
+    // later group's inside the sweep of the group before it, into the registers that sweep has just consumed (sweep_group).
+    // Otherwise (register-resident weight rows): read at the group's start into registers that live for that group only.
+    float4 old[NU][SW_MT];
+    if (DKPF && NGRP > 0) {
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu)
+#pragma unroll
+            for (int mt = 0; mt < SW_MT; ++mt)
+                old[nu][mt] = *reinterpret_cast<const float4*>(p.dkT + ((g0 + 4 * min(mt, MTB - 1)) * A + acol[nu]) * 4);
+    }
     for (int g = 0; g < NGRP; ++g) {
         const int MTg = min(SW_MT, MTB - SW_MT * g);
         const int fg0 = GF * g;                                          // first frame of the group inside the tile
-        // dkey of the group's elements: requested now, added and stored inside the sweep; DKPF (tiles streamed from HBM: the
-        // latency of the read would be exposed once per group): requested one group ahead
-        float4 old[NU][SW_MT];
-        if (!DKPF || g == 0) {
-#pragma unroll
-            for (int nu = 0; nu < NU; ++nu)
-#pragma unroll
-                for (int mt = 0; mt < SW_MT; ++mt)
-                    old[nu][mt] = *reinterpret_cast<const float4*>(p.dkT + ((g0 + 4 * min(SW_MT * g + mt, MTB - 1)) * A + acol[nu]) * 4);
-        } else {
-#pragma unroll
-            for (int nu = 0; nu < NU; ++nu)
-#pragma unroll
-                for (int mt = 0; mt < SW_MT; ++mt) old[nu][mt] = oldn[nu][mt];
-        }
-        if (DKPF && g + 1 < NGRP) {
-#pragma unroll
-            for (int nu = 0; nu < NU; ++nu)
-#pragma unroll
-                for (int mt = 0; mt < SW_MT; ++mt)
-                    oldn[nu][mt] = *reinterpret_cast<const float4*>(p.dkT + ((g0 + 4 * min(SW_MT * (g + 1) + mt, MTB - 1)) * A + acol[nu]) * 4);
-        }
         float cn0 = 0.f, cn1 = 0.f;
         if (COMPUTE && g + 1 < NGRP) {
             const int fa = tau0 + fg0 + GF + cvf0, fb = tau0 + fg0 + GF + cvf1;
@@ -866,8 +857,20 @@ __device__ __forceinline__ void sweep_tile(const PSB& p, Sweep<NU>& S, const flo
 #pragma unroll
         for (int nu = 0; nu < NU; ++nu) dqg[nu] = 0.f;
         const unsigned short* key_next = (g + 1 < NGRP) ? p.key16t + (g0 + 4 * SW_MT * (g + 1)) * A * 4 : nullptr;
-        sweep_group<NU>(S, qa, dqg, old, kf, p.dkT + (g0 + 4 * SW_MT * g) * A * 4, key_next, acol, A, MTB - SW_MT * (g + 1),
-                        nu_cnt, wave, nw, MTg, AP, s_cvx, s_cvT, s_de + fg0, s_dl, lane);
+        if constexpr (DKPF) {
+            const float* dk_next = (g + 1 < NGRP) ? p.dkT + (g0 + 4 * SW_MT * (g + 1)) * A * 4 : nullptr;
+            sweep_group<NU>(S, qa, dqg, old, kf, p.dkT + (g0 + 4 * SW_MT * g) * A * 4, dk_next, key_next, acol, A, MTB - SW_MT * (g + 1),
+                            nu_cnt, wave, nw, MTg, AP, s_cvx, s_cvT, s_de + fg0, s_dl, lane);
+        } else {
+            float4 og[NU][SW_MT];
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu)
+#pragma unroll
+                for (int mt = 0; mt < SW_MT; ++mt)
+                    og[nu][mt] = *reinterpret_cast<const float4*>(p.dkT + ((g0 + 4 * min(SW_MT * g + mt, MTB - 1)) * A + acol[nu]) * 4);
+            sweep_group<NU>(S, qa, dqg, og, kf, p.dkT + (g0 + 4 * SW_MT * g) * A * 4, nullptr, key_next, acol, A, MTB - SW_MT * (g + 1),
+                            nu_cnt, wave, nw, MTg, AP, s_cvx, s_cvT, s_de + fg0, s_dl, lane);
+        }
 #pragma unroll
         for (int nu = 0; nu < NU; ++nu) dqt[nu] += dqg[nu];
         __syncthreads();                                                // G1: s_dl of the group complete
@@ -945,8 +948,11 @@ __device__ __forceinline__ void sweep_tile(const PSB& p, Sweep<NU>& S, const flo
 
 // RESIDENT: the workgroup's CPW + UPW rows of the transposed cell weights fit the registers (B <= 16: at most 59 rows); otherwise
 // every row is streamed from L2 and the 80 registers go to prefetching (dkey one group ahead)
-template <int KNMAX, bool RESIDENT>
+// RC / RP: register-resident rows per compute / polling wave: (4, 5) = the 33 rows of a B <= 8 plan (NT = 30), (0, 0) = every row
+// streamed from L2 (the 8 + 9 rows of dec_bwd_persist would spill 110 registers around the sweep here and lose to streaming).
+template <int KNMAX, int RC, int RP>
 __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
+    constexpr bool RESIDENT = RC > 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned s_bar;
     __shared__ float s_red[8];
@@ -1013,7 +1019,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
     for (int i = tid; i < NDE; i += blockDim.x) s_de[i] = 0.f;
     const int u_base = j * p.UPW, c_base = j * p.CPW;
     const int nout = p.CPW + p.UPW;
-    const int RES = RESIDENT ? RCB * ncw + RPB * NPB : 0;                 // register-resident outputs of P1
+    const int RES = RC * ncw + RP * NPB;                                  // register-resident outputs of P1
     const int nunits = (A + 15) >> 4;
     const int nu_cnt = (nunits - wave + nw - 1) / nw;
     const int qsub = lane >> 4, csub = lane & 15;
@@ -1025,9 +1031,9 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
     if (wave >= ncw) {
         // =========================== polling role ===========================
         const int gt = tid - nct, np = 64 * NPB;
-        const int obase = RCB * ncw + (wave - ncw);
-        uint2 wreg[RESIDENT ? RPB : 1][KCHB];
-        if (RESIDENT) { DPB_WLOAD((RESIDENT ? RPB : 1), obase, NPB) }
+        const int obase = RC * ncw + (wave - ncw);
+        uint2 wreg[RESIDENT ? RP : 1][KCHB];
+        if (RESIDENT) { DPB_WLOAD((RESIDENT ? RP : 1), obase, NPB) }
         Sweep<SW_NUP> S;
         sweep_init<KNMAX>(S, p.w.Wproj, p.w.wg, A, Kn, wave, nw, lane);
         for (int t = L - 1; t >= 0; --t) {
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
             const u64 want = pair_want(seq_of(s), epoch_);
             u64* base = xb(s & 1);
             __syncthreads();                                            // Ba: s_dg16 holds the gate gradients of step t
-            if (RESIDENT) { DPB_P1((RESIDENT ? RPB : 1), obase, NPB) }
+            if (RESIDENT) { DPB_P1((RESIDENT ? RP : 1), obase, NPB) }
             DSB_P1_EXTRA(wave, nw)
             __syncthreads();                                            // Bb: s_out complete
             poll_copy<4>(base + offC, NT * p.CG2 / 2, s_crec, gt, np, want, p.status);
@@ -1118,8 +1124,8 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
 
     // =========================== compute role ===========================
     unsigned gen = 0;
-    uint2 wreg[RESIDENT ? RCB : 1][KCHB];
-    if (RESIDENT) { DPB_WLOAD((RESIDENT ? RCB : 1), wave, ncw) }
+    uint2 wreg[RESIDENT ? RC : 1][KCHB];
+    if (RESIDENT) { DPB_WLOAD((RESIDENT ? RC : 1), wave, ncw) }
     Sweep<SW_NU> S;
     sweep_init<KNMAX>(S, p.w.Wproj, p.w.wg, A, Kn, wave, nw, lane);
     const int a = tid;
@@ -1173,7 +1179,7 @@ __global__ __launch_bounds__(512) void dec_bwd_stream(PSB p) {
         __syncthreads();                                                // Ba
         DP_MARK(2)
         // ---- P1: dctx slice and the recurrent part of dh_{t-1} for the own units
-        if (RESIDENT) { DPB_P1((RESIDENT ? RCB : 1), wave, ncw) }
+        if (RESIDENT) { DPB_P1((RESIDENT ? RC : 1), wave, ncw) }
         DSB_P1_EXTRA(wave, nw)
         DP_MARK(3)
         __syncthreads();                                                // Bb
@@ -1495,17 +1501,21 @@ int dec_bwd_streamed(const asr_dec_dims_t& d, const asr_dec_weights_t& w, const 
           slot, pl.NT, pl.TEB, pl.UPW, pl.CPW, pl.R4, pl.CG2, pl.QG2, pl.VG2, pl.NG2, allow, delay};
     const int cpx = cdiv(d.B, 8), ncw = cdiv(d.A, 64);
     const dim3 grid(8 * cpx * pl.NT), block(64 * (ncw + NPB));
-#define DSB_LAUNCH(KN_, RES_)                                                                                                   \
+#define DSB_LAUNCH(KN_, RC_, RP_)                                                                                               \
     {                                                                                                                           \
         static unsigned char attr_[32];                                                                                         \
-        if (first_on_device(attr_)) hipFuncSetAttribute((const void*)dec_bwd_stream<KN_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
-        if (!grid_resident(dec_bwd_stream<KN_, RES_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                             \
-        hipLaunchKernelGGL((dec_bwd_stream<KN_, RES_>), grid, block, pl.lds, st, p);                                            \
+        if (first_on_device(attr_)) hipFuncSetAttribute((const void*)dec_bwd_stream<KN_, RC_, RP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); \
+        if (!grid_resident(dec_bwd_stream<KN_, RC_, RP_>, (int)grid.x, (int)block.x, pl.lds)) return 1;                         \
+        hipLaunchKernelGGL((dec_bwd_stream<KN_, RC_, RP_>), grid, block, pl.lds, st, p);                                        \
         hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, st, status);                                                 \
     }
-    const bool resident = pl.CPW + pl.UPW <= RCB * ncw + RPB * NPB;
-    if (d.Kn <= 4) { if (resident) DSB_LAUNCH(4, true) else DSB_LAUNCH(4, false) }
-    else { if (resident) DSB_LAUNCH(10, true) else DSB_LAUNCH(10, false) }
+    const int nrows = pl.CPW + pl.UPW;
+    // measured (tools/diag_dec_stream.py, us per step): B=8 x T'=1225 half-resident 29.8 / all rows streamed 30.1 / the full resident
+    // set of dec_bwd_persist (8 + 9 rows per wave, 110 spilled registers here) 34.5; B=16 x T'=1225 streamed 35.2 / full set 37.8
+    int res = (nrows <= 4 * ncw + 5 * NPB) ? 1 : 0;
+    if (const char* e = getenv("ASR_DEC_STREAM_RES")) { if (atoi(e) == 0) res = 0; }        // experiments: stream every row
+    if (d.Kn <= 4) { if (res == 1) DSB_LAUNCH(4, 4, 5) else DSB_LAUNCH(4, 0, 0) }
+    else { if (res == 1) DSB_LAUNCH(10, 4, 5) else DSB_LAUNCH(10, 0, 0) }
 #undef DSB_LAUNCH
     hipLaunchKernelGGL(dkey_untranspose_kernel, dim3(2048), dim3(256), 0, st, dkT, dkey, d.B, d.Tp, d.A, (long)pl.NT * pl.TEB / 4);
     hipError_t e = hipGetLastError();

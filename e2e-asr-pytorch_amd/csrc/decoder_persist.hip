@@ -462,19 +462,25 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
         compute_barrier(&s_bar, gen);                                   // c5: s_x holds [ctx_t | h_{t-1}]
         DP_MARK(10)
         // ---- LSTM cell: gate rows r = g*UPW + ul of this workgroup, RPW rows per wave, lanes over 16-byte chunks
+        //      RBF = 10 rows per batch of loads: the 10 rows per wave of the bench shape (80 rows, 8 waves) are ONE L2 round trip, not
+        //      two.  The phase stays near the L2's bandwidth: 32 workgroups per XCD x 151 KB of rows per step.  Keeping rows in registers
+        //      across all twelve waves was tried (round 3): the 168-register budget holds 40 of the 80 rows without spilling
+        //      (4 per polling wave beside its 10-wide polls, 3 per compute wave); cell rows 2.3 -> 1.9 us, but the compute waves' other
+        //      phases lost as much (stats + ctx 1.2 -> 1.8 us) - not adopted.
         {
+            constexpr int RBF = 10;
             const int nchunk = p.KCP >> 3;
             float mine = 0.f;
 #pragma unroll 1
-            for (int bt = 0; bt * RB < RPW; ++bt) {
-                float part[RB];
+            for (int bt = 0; bt * RBF < RPW; ++bt) {
+                float part[RBF];
 #pragma unroll
-                for (int rr = 0; rr < RB; ++rr) part[rr] = 0.f;
+                for (int rr = 0; rr < RBF; ++rr) part[rr] = 0.f;
                 for (int ch0 = lane; ch0 < nchunk; ch0 += 128) {
-                    uint4 wv[RB][2];
+                    uint4 wv[RBF][2];
 #pragma unroll
-                    for (int rr = 0; rr < RB; ++rr) {
-                        const int r = min(wave * RPW + bt * RB + rr, 4 * p.UPW - 1);
+                    for (int rr = 0; rr < RBF; ++rr) {
+                        const int r = min(wave * RPW + bt * RBF + rr, 4 * p.UPW - 1);
                         const int g = r / p.UPW, ul = r - g * p.UPW;
                         const long grow = (long)g * Dd + min(u_base + ul, Dd - 1);
 #pragma unroll
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                             const float4 xa = *reinterpret_cast<const float4*>(s_x + 8 * ch);
                             const float4 xb4 = *reinterpret_cast<const float4*>(s_x + 8 * ch + 4);
 #pragma unroll
-                            for (int rr = 0; rr < RB; ++rr) {
+                            for (int rr = 0; rr < RBF; ++rr) {
                                 const uint4 w4 = wv[rr][h2];
                                 part[rr] += __uint_as_float(w4.x << 16) * xa.x + __uint_as_float(w4.x & 0xffff0000u) * xa.y +
                                             __uint_as_float(w4.y << 16) * xa.z + __uint_as_float(w4.y & 0xffff0000u) * xa.w +
@@ -499,9 +505,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                     }
                 }
 #pragma unroll
-                for (int rr = 0; rr < RB; ++rr) {
+                for (int rr = 0; rr < RBF; ++rr) {
                     const float sv = wave_sum_dpp(part[rr]);
-                    if (lane == bt * RB + rr) mine = sv;
+                    if (lane == bt * RBF + rr) mine = sv;
                 }
             }
             const int r = wave * RPW + lane;

@@ -51,6 +51,10 @@ __device__ __forceinline__ void jitter3(unsigned k, unsigned step, unsigned epoc
 #endif
 
 constexpr int HDR_BYTES = 1024;         // status block: abort word, per-group consensus words (u64 8..15), modes (26..33), diag (64..)
+// TWO status blocks per workspace, used by launch epoch parity: a launch works in block (epoch & 1) and clears the OTHER one for
+// its successor (first workgroup, before anything else) - the per-launch `hipMemsetAsync` of the header is gone (eight fill
+// launches per training step on the critical stream).  A fresh / scrubbed workspace is all zero.
+constexpr int HDR_SLOTS = 2;
 constexpr int FWD_REGIONS = 8, BWD_REGIONS = 2;
 
 struct P3 {
@@ -60,6 +64,7 @@ struct P3 {
     float* c;                // (B,T,ND,H)
     u64* xbuf;               // exchange region of this launch
     unsigned* abort_flag;
+    unsigned* clear_next;    // status block of the next launch on this workspace: cleared by workgroup 0
     int B, T, H, ND, P, NS, BS;
     int allow_local, poll_delay;
     unsigned epoch;
@@ -109,6 +114,7 @@ __device__ __forceinline__ void publish_pair(__amdgpu_buffer_rsrc_t rsrc, unsign
 // Exchange region: [group][parity][b (16)][H/4] granules.
 template <int NKS, int CH>            // CH = 16-byte granule pairs per gather thread: ceil(rows * (H/8) / 256)
 __global__ __launch_bounds__(512) void lstm_fwd_p3(P3 p) {
+    if (blockIdx.x == 0 && threadIdx.x < HDR_BYTES / 4) p.clear_next[threadIdx.x] = 0u;      // the successor's status block (see HDR_SLOTS)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = p.H, T = p.T, ND = p.ND;
     const int gid = blockIdx.x & 7, pw = blockIdx.x >> 3;
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_p3(P3 p) {
 // Exchange region: [group][parity][consumer][producer][b (BS)][8 granules of two fp32].
 template <int NTO>
 __global__ __launch_bounds__(512) void lstm_bwd_p3(P3 p) {
+    if (blockIdx.x == 0 && threadIdx.x < HDR_BYTES / 4) p.clear_next[threadIdx.x] = 0u;      // the successor's status block (see HDR_SLOTS)
     __shared__ __attribute__((aligned(16))) __bf16 tile[16 * 72];     // [b][64 + 8] dgates of this slice, k = 4*unit + gate
     __shared__ __attribute__((aligned(16))) float s_part[4 * 256];   // [producer group][b][16]
     const int H = p.H, T = p.T, ND = p.ND, P = p.P, BS = p.BS;
@@ -487,6 +494,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_p3(P3 p) {
 // Exchange region: [group][parity][producer][row < nb][16 units] pairs of granules {d_i, d_f}, {d_g, d_o}.
 template <int NTO>
 __global__ __launch_bounds__(512) void lstm_bwd_p4(P3 p) {
+    if (blockIdx.x == 0 && threadIdx.x < HDR_BYTES / 4) p.clear_next[threadIdx.x] = 0u;      // the successor's status block (see HDR_SLOTS)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
     __shared__ __attribute__((aligned(16))) float s_part[4 * 256];   // [compute wave][b][16 units] partial dh
     constexpr int KSW = 2 * NTO;                                      // k-steps of 32 gate rows per compute wave (4 KSW >= 2 P)
@@ -714,7 +722,7 @@ bool lstm3_shape_ok(int B, int H, int ND) { return H % 16 == 0 && H >= 16 && H <
 
 size_t lstm_persist3_workspace_bytes(int B, int H, int ND, int bwd) {
     if (!lstm3_shape_ok(B, H, ND)) return 0;
-    return HDR_BYTES + (bwd ? BWD_REGIONS * bwd3_region_bytes(H, slice_rows(B, ND)) : FWD_REGIONS * fwd3_region_bytes(H));
+    return HDR_SLOTS * HDR_BYTES + (bwd ? BWD_REGIONS * bwd3_region_bytes(H, slice_rows(B, ND)) : FWD_REGIONS * fwd3_region_bytes(H));
 }
 
 #define FWD3_LAUNCH(NKS_, CH_)                                                                                              \
@@ -754,9 +762,10 @@ int lstm_fwd_persistent3(unsigned short* gates, const float* whh, unsigned short
     if (ws_bytes < lstm_persist3_workspace_bytes(B, H, ND, 0)) return 1;
     const int NS = 8 / ND, BS = slice_rows(B, ND);
     const int groups = ND * ((B + BS - 1) / BS);
-    hipMemsetAsync(ws, 0, HDR_BYTES, st);
-    u64* region = (u64*)((char*)ws + HDR_BYTES + (size_t)((epoch >> 2) % FWD_REGIONS) * fwd3_region_bytes(H));
-    P3 p{gates, whh, y, c, region, (unsigned*)ws, B, T, H, ND, H / 16, NS, BS, allow_local3(), poll_delay3(false), epoch, nullptr, 0u};
+    unsigned* hdr = (unsigned*)((char*)ws + (size_t)(epoch & 1u) * HDR_BYTES);
+    unsigned* hdr_next = (unsigned*)((char*)ws + (size_t)((epoch + 1u) & 1u) * HDR_BYTES);
+    u64* region = (u64*)((char*)ws + HDR_SLOTS * HDR_BYTES + (size_t)((epoch >> 2) % FWD_REGIONS) * fwd3_region_bytes(H));
+    P3 p{gates, whh, y, c, region, hdr, hdr_next, B, T, H, ND, H / 16, NS, BS, allow_local3(), poll_delay3(false), epoch, nullptr, 0u};
     const int nks = (H + 31) / 32;
     FWD3_CASE(1) FWD3_CASE(2) FWD3_CASE(4) FWD3_CASE(6) FWD3_CASE(8) FWD3_CASE(10) FWD3_CASE(12) FWD3_CASE(16)
     return 1;
@@ -772,11 +781,12 @@ int lstm_bwd_persistent3(unsigned short* gates, const float* whh, const unsigned
     if (ws_bytes < lstm_persist3_workspace_bytes(B, H, ND, 1)) return 1;
     const int NS = 8 / ND, BS = slice_rows(B, ND);
     const int groups = ND * ((B + BS - 1) / BS);
-    hipMemsetAsync(ws, 0, HDR_BYTES, st);
-    u64* region = (u64*)((char*)ws + HDR_BYTES + (size_t)((epoch >> 4) % BWD_REGIONS) * bwd3_region_bytes(H, BS));
+    unsigned* hdr = (unsigned*)((char*)ws + (size_t)(epoch & 1u) * HDR_BYTES);
+    unsigned* hdr_next = (unsigned*)((char*)ws + (size_t)((epoch + 1u) & 1u) * HDR_BYTES);
+    u64* region = (u64*)((char*)ws + HDR_SLOTS * HDR_BYTES + (size_t)((epoch >> 4) % BWD_REGIONS) * bwd3_region_bytes(H, BS));
     const size_t rbytes = bwd3_region_bytes(H, BS);
     if (rbytes >= (1ull << 31)) return 1;
-    P3 p{gates, whh, const_cast<unsigned short*>(dy), const_cast<float*>(c), region, (unsigned*)ws, B, T, H, ND, H / 16, NS, BS,
+    P3 p{gates, whh, const_cast<unsigned short*>(dy), const_cast<float*>(c), region, hdr, hdr_next, B, T, H, ND, H / 16, NS, BS,
          allow_local3(), poll_delay3(true), epoch, (unsigned char*)region + rbytes - bwd3_dump_bytes(H), (unsigned)rbytes};
     const int nto = (p.P + 3) / 4;
     BWD3_CASE(1) BWD3_CASE(2) BWD3_CASE(3) BWD3_CASE(4) BWD3_CASE(5) BWD3_CASE(6) BWD3_CASE(8)

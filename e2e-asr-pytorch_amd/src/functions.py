@@ -282,11 +282,12 @@ class RNNLayerFastFn(torch.autograd.Function):
         y = _empty16((B, T + 2, D), x16)          # rows 0 and T+1 (time pads) are zeroed by the recurrence kernel
         c = _empty((B, T, ND, Hd), x16)
         ws, epoch = _ws16(layer, B, 0)
-        H.abort_guard(ws)
+        # two status blocks by launch parity (include/asr_hip.h): this launch reports in block epoch & 1 and clears the other one
+        H.abort_guard(ws, ((epoch + 1) & 1) * 1024)
         reserved = 64 if (layer.dp is not None and layer.dp.world > 1) else 0
         H.call('asr_lstm16_fwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(y), H.ptr(c), B, T, Hd, ND,
                H.ptr(ws), ws.numel(), epoch, reserved, st)
-        H.watch_abort(ws)
+        H.watch_abort(ws, (epoch & 1) * 1024)
         layer.last_ws = ws
         p = float(layer.dropout) if train else 0.0
         r = layer.sample_rate
@@ -348,7 +349,7 @@ class RNNLayerFastFn(torch.autograd.Function):
         dy = _empty16((B, T, D), x16)
         H.call('asr_dropout_downsample16_bwd', H.ptr(dz), H.ptr(dy), B, T, D, T2, layer.sample_rate, 0, p, seed, st)
         ws, epoch = _ws16(layer, B, 1)
-        H.abort_guard(ws)
+        H.abort_guard(ws, ((epoch + 1) & 1) * 1024)
         if overlap:
             pre = torch.cuda.Event()
             pre.record(torch.cuda.current_stream())
@@ -359,7 +360,7 @@ class RNNLayerFastFn(torch.autograd.Function):
         else:
             H.call('asr_lstm16_bwd', H.ptr(gates), H.ptr(layer.w_hh_cat), H.ptr(dy), H.ptr(c), B, T, Hd, ND,
                    H.ptr(ws), ws.numel(), epoch, reserved, st)
-        H.watch_abort(ws)
+        H.watch_abort(ws, (epoch & 1) * 1024)
         layer.last_ws_bwd = ws
         # gates now holds the gradient wrt the gate pre-activations (gate-minor); parameter gradients in reference row order
         dx = None

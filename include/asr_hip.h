@@ -110,8 +110,10 @@ int asr_lstm_bwd(float* gates, const float* whh, const float* dy, const float* c
  * `epoch` = number of launches this workspace has seen (the caller increments it): it is folded into the granule tags
  * and selects the exchange region, so a (region, tag) pair repeats only every 32 launches of the same workspace.
  * `reserved_cus`: compute units another stream may occupy meanwhile (data-parallel all-reduce): the launch is refused
- * (ASR_E_UNSUPPORTED) unless all its workgroups fit beside them (occupancy query).  The first 32-bit word of the
- * workspace is the abort word (see "Status word" below).
+ * (ASR_E_UNSUPPORTED) unless all its workgroups fit beside them (occupancy query).  The workspace starts with TWO 1 KB status
+ * blocks used by launch parity: a launch reports in block (epoch & 1) - its first 32-bit word is the abort word (see "Status
+ * word" below) - and clears the other block for its successor, so consecutive launches on a workspace MUST carry consecutive
+ * epochs and an uncollected abort word of launch k-1 must be folded before launch k+1 starts (it lives in the block k+1 clears).
  */
 size_t asr_lstm16_workspace_bytes(int B, int H, int ND, int backward);
 int asr_lstm16_fwd(void* gates16, const float* whh, void* y16, float* c, int B, int T, int H, int ND,

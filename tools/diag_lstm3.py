@@ -33,8 +33,8 @@ NAMES = {'fwd': ['C: wait tile (barrier)', 'C: lds read+mfma+cell', 'C: shuffle+
                  'G: sleep+poll+sum', 'G: lds write', 'G: barrierA', 'G: barrierB', '-', '-', '-', '-']}
 
 
-def report(tag, ms, ws):
-    st = ws[:1024].view(torch.int64).cpu().tolist()
+def report(tag, ms, ws, epoch):
+    st = ws[(epoch & 1) * 1024:][:1024].view(torch.int64).cpu().tolist()          # the launch's status block (parity of its epoch)
     print('%s: %.3f ms (%.3f us/step) abort=%d modes=%s' % (tag, ms, ms * 1e3 / T, st[0] & 0xffffffff, st[26:34]))
     if diag:
         for k, nm in enumerate(NAMES[tag]):
@@ -51,5 +51,5 @@ for it in range(3):
     H.call('asr_lstm16_bwd', H.ptr(g2), H.ptr(whh), H.ptr(dy), H.ptr(c), B, T, Hd, ND, H.ptr(wsb), nb, it + 1, 0, H.stream_ptr())
     e[2].record(); torch.cuda.synchronize()
     if it > 0:
-        report('fwd', e[0].elapsed_time(e[1]), wsf)
-        report('bwd', e[1].elapsed_time(e[2]), wsb)
+        report('fwd', e[0].elapsed_time(e[1]), wsf, it + 1)
+        report('bwd', e[1].elapsed_time(e[2]), wsb, it + 1)

@@ -1172,19 +1172,21 @@ BwdLayout bwd_layout(const asr_dec_dims_t& d) {
     o.nch = (int)(256 / d.B > 0 ? 256 / d.B : 1);
     if (o.nch > d.L) o.nch = d.L;
     o.lds_w = sizeof(float) * ((size_t)((d.Tp + 2 * d.Ks + 8 + 3) & ~3) + (size_t)d.Kn * d.Tp);
+    // the zero-initialised accumulators first and back to back, the persistent launch's status block right behind them: ONE fill
+    // from `dhs` to `pwork + 256` at the start of a call (five separate fills before)
     o.dhs = take((size_t)d.B * d.L * d.NL * d.Dd);
-    o.dxin = take((size_t)d.B * d.L * XW);
     o.dq = take((size_t)d.B * d.L * d.A);
     o.dkey = take((size_t)d.B * d.Tp * d.A);
-    o.dkeypre = take((size_t)d.B * d.Tp * d.A);
-    o.datt_next = take((size_t)d.B * d.Tp);
-    o.dcf = take((size_t)d.NL * d.B * d.Dd);
-    o.wq_t = take((size_t)d.Q * d.A);
     o.ntp = dec_bwd_persist_tiles_fw(d);
     o.ntp_max = dec_bwd_persist_tiles_max_fw(d);
     o.slots = take((size_t)d.B * (o.nte > o.ntp_max ? o.nte : o.ntp_max) * o.slot);
     o.pwork_bytes = dec_bwd_persist_work_bytes_fw(d);
     o.pwork = take(o.pwork_bytes / sizeof(float) + 64);
+    o.dxin = take((size_t)d.B * d.L * XW);
+    o.dkeypre = take((size_t)d.B * d.Tp * d.A);
+    o.datt_next = take((size_t)d.B * d.Tp);
+    o.dcf = take((size_t)d.NL * d.B * d.Dd);
+    o.wq_t = take((size_t)d.Q * d.A);
     o.wslots = take((size_t)d.B * o.nch * d.Kn * taps);
     for (int l = 0; l < d.NL; ++l) o.wcat[l] = take((size_t)((l == 0 ? XW : d.Dd) + d.Dd) * 4 * d.Dd);
     o.total = off;
@@ -1425,8 +1427,6 @@ extern "C" int asr_att_decoder_bwd_ex(const asr_dec_dims_t* dims, const asr_dec_
     const bool bf = (prec == ASR_BF16);
     const long SW = (long)d.NL * d.Dd;
     const int BL = d.B * d.L;
-    // abort word of the persistent launch's status block: defined (0) after every call, see asr_att_decoder_fwd
-    if (lay.ntp > 0 && lay.pwork + 256 <= lay.total) hipMemsetAsync(ws + lay.pwork, 0, 256, st);
 
     DecB p;
     p.f = DecP{d, *weights, *state, enc, enc_len};
@@ -1439,11 +1439,9 @@ extern "C" int asr_att_decoder_bwd_ex(const asr_dec_dims_t* dims, const asr_dec_
     float* dkeypre = (float*)(ws + lay.dkeypre);
     for (int l = 0; l < ASR_MAX_DEC_LAYERS; ++l) p.wcatT[l] = (l < d.NL) ? (float*)(ws + lay.wcat[l]) : nullptr;
 
-    // zero-initialised accumulators: dhs, dq, dkey, slots  (dxin is fully written by the loop)
-    hipMemsetAsync(p.dhs, 0, sizeof(float) * (size_t)BL * SW, st);
-    hipMemsetAsync(p.dkey, 0, sizeof(float) * (size_t)d.B * d.Tp * d.A, st);
-    hipMemsetAsync(p.dq, 0, sizeof(float) * (size_t)BL * d.A, st);
-    hipMemsetAsync(p.slots, 0, sizeof(float) * (size_t)d.B * (lay.nte > lay.ntp_max ? lay.nte : lay.ntp_max) * lay.slot, st);
+    // zero-initialised accumulators dhs, dq, dkey, slots (dxin is fully written by the loop) and the abort word of the persistent
+    // launch's status block (defined, 0, after every call - see asr_att_decoder_fwd): contiguous in the layout, one fill
+    hipMemsetAsync(ws + lay.dhs, 0, lay.pwork + 256 - lay.dhs, st);
 
     // transposed weights so that every per-step contraction is K-contiguous
     for (int l = 0; l < d.NL; ++l) {

@@ -227,3 +227,35 @@ def test_hip_path_refuses_cpu_tensors(golden_dir):
     cfg, sd, model = build(meta, 'fp32')
     with pytest.raises(RuntimeError):
         model(torch.from_numpy(z['feat']), torch.from_numpy(z['feat_len']), 3)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_extremely_ragged_batch_vs_oracle(golden_dir, prec):
+    """Edge of the batch contract (src/collect_batch.py:44-48): a batch whose shortest utterance keeps ONE encoder frame and one
+    token beside a full-length one (attention over a single frame, location filter wider than the utterance, CTC with T' = L = 1),
+    and a single-utterance batch.  Against the oracle on the same inputs (no reference fixture holds these shapes)."""
+    meta, z = load(golden_dir, 'g1_small_c2')
+    cfg, sd, model = build(meta, prec)
+    model.eval()
+    g = np.random.Generator(np.random.PCG64(77))
+    for lens, tls in (([37, 9, 3], [7, 2, 1]), ([21], [5])):
+        B, T = len(lens), lens[0]
+        feat = g.random((B, T, meta['D']), dtype=np.float32)
+        txt = np.zeros((B, tls[0]), dtype=np.int64)
+        for b in range(B):
+            feat[b, lens[b]:] = 0.0
+            txt[b, :tls[b] - 1] = g.integers(3, meta['V'], size=tls[b] - 1)
+            txt[b, tls[b] - 1] = 1
+        feat, flen, txt = torch.from_numpy(feat), torch.tensor(lens, dtype=torch.int64), torch.from_numpy(txt)
+        res = hip_step(model, feat, flen, txt, False)
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = O.asr_losses(feat, flen, txt, P, cfg, label_smoothing=False)
+        ref['total_loss'].backward()
+        assert torch.isfinite(ref['total_loss']), 'the case must be CTC-feasible'
+        ref_out = {k: ref[k].detach().numpy() for k in ('ctc_output', 'att_output', 'att_seq')}
+        for k in ('ctc_loss', 'att_loss', 'total_loss'):
+            ref_out[k] = float(ref[k].detach())
+        ref_grads = {k: (P[k].grad.numpy() if P[k].grad is not None else np.zeros(tuple(P[k].shape), np.float32)) for k in P}
+        report = []
+        compare(model, res, ref_out, ref_grads, prec, report)
+        finish(report)

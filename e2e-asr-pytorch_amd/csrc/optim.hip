@@ -141,6 +141,30 @@ extern "C" int asr_sumsq(const float* x, long n, double* out, asr_stream_t strea
     return ASR_OK;
 }
 
+namespace {
+// out[i] = in[i] * alpha[0] with the factor in DEVICE memory: the backward of a loss kernel under the loss mix (grad_output is a
+// device scalar; torch's `grad * gout` was the last elementwise ATen arithmetic of the step)
+__global__ void scale_dev_kernel(const float* __restrict__ in, float* __restrict__ out, long n, const float* __restrict__ alpha) {
+    const float a = alpha[0];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i] * a;
+}
+// out[0] = a[0] * wa[0] (+ b[0] * wb[0]): total = w ctc + (1 - w) att (bin/train_asr.py:246) and its backward, scalars on the device
+__global__ void loss_mix_kernel(const float* a, const float* wa, const float* b, const float* wb, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = a[0] * wa[0] + (b ? b[0] * wb[0] : 0.f);
+}
+}  // namespace
+extern "C" int asr_scale_dev(const float* in, float* out, long n, const float* alpha, asr_stream_t stream) {
+    ASR_REQUIRE(in && out && alpha && n > 0, ASR_E_ARG, "asr_scale_dev: bad args");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, alpha);
+    ASR_LAUNCH_CHECK("asr_scale_dev");
+    return ASR_OK;
+}
+extern "C" int asr_loss_mix(const float* a, const float* wa, const float* b, const float* wb, float* out, asr_stream_t stream) {
+    ASR_REQUIRE(a && wa && out && (!b || wb), ASR_E_ARG, "asr_loss_mix: bad args");
+    hipLaunchKernelGGL(loss_mix_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, wa, b, wb, out);
+    ASR_LAUNCH_CHECK("asr_loss_mix");
+    return ASR_OK;
+}
 extern "C" int asr_scale(float* x, long n, float k, asr_stream_t stream) {
     ASR_REQUIRE(x && n > 0, ASR_E_ARG, "asr_scale: bad args");
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, k);

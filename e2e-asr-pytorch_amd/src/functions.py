@@ -437,6 +437,51 @@ class CTCHeadFn(torch.autograd.Function):
         return None, denc, None, None, None
 
 
+def scale_by_device_scalar(x, alpha):
+    """x * alpha with alpha a one-element device tensor (the grad_output of a loss): asr_scale_dev."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    a = alpha.reshape(1).to(torch.float32).contiguous()
+    H.call('asr_scale_dev', H.ptr(x), H.ptr(out), x.numel(), H.ptr(a), H.stream_ptr())
+    return out
+
+
+_LOSS_W = {}
+
+
+def loss_weight(value, device):
+    """A cached one-element device tensor holding a host constant (loss weights)."""
+    key = (float(value), str(device))
+    if key not in _LOSS_W:
+        _LOSS_W[key] = torch.full((1,), float(value), dtype=torch.float32, device=device)
+    return _LOSS_W[key]
+
+
+class LossMixFn(torch.autograd.Function):
+    """total = wa a + wb b (bin/train_asr.py:238,246) with the weights as one-element device tensors (under data parallelism the
+    attention weight comes out of an all-reduce); forward and backward are the one-thread kernel asr_loss_mix."""
+
+    @staticmethod
+    def forward(ctx, a, wa, b, wb):
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        H.call('asr_loss_mix', H.ptr(a), H.ptr(wa), H.ptr(b), H.ptr(wb) if b is not None else None, H.ptr(out), H.stream_ptr())
+        ctx.has_b = b is not None
+        ctx.save_for_backward(wa, *( [wb] if b is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sv = ctx.saved_tensors
+        g = g.reshape(1).to(torch.float32).contiguous()
+        ga = torch.empty((), dtype=torch.float32, device=g.device)
+        H.call('asr_loss_mix', H.ptr(g), H.ptr(sv[0]), None, None, H.ptr(ga), H.stream_ptr())
+        gb = None
+        if ctx.has_b:
+            gb = torch.empty((), dtype=torch.float32, device=g.device)
+            H.call('asr_loss_mix', H.ptr(g), H.ptr(sv[1]), None, None, H.ptr(gb), H.stream_ptr())
+        return ga, None, gb, None
+
+
 # --------------------------------------------------------------------------------------------------
 # CTC loss (torch.nn.CTCLoss(blank=0, zero_infinity=False), bin/train_asr.py:135,237)
 # --------------------------------------------------------------------------------------------------
@@ -471,7 +516,7 @@ class CTCLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
-        return grad * gout, None, None, None
+        return scale_by_device_scalar(grad, gout), None, None, None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -495,7 +540,7 @@ class SeqLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (dl,) = ctx.saved_tensors
-        return dl * gout, None, None, None, None
+        return scale_by_device_scalar(dl, gout), None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------

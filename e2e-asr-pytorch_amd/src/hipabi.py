@@ -113,6 +113,8 @@ SIGNATURES = {
     'asr_gru_bwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     'asr_sumsq': [_vp, _l, _vp, _vp],
     'asr_scale': [_vp, _l, _f, _vp],
+    'asr_scale_dev': [_vp, _vp, _l, _vp, _vp],
+    'asr_loss_mix': [_vp, _vp, _vp, _vp, _vp, _vp],
     'asr_adadelta_step': [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp],
     'asr_adam_step': [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _f, _vp, _vp, _vp],
     'asr_embedding_bwd': [_vp, _l, _vp, _vp, _i, _i, _i, _vp],

@@ -306,6 +306,11 @@ int asr_att_decoder_bwd_params(const asr_dec_dims_t* dims, const asr_dec_weights
  */
 int asr_sumsq(const float* x, long n, double* out, asr_stream_t stream);
 int asr_scale(float* x, long n, float k, asr_stream_t stream);
+/* The loss mix with every scalar on the device (bin/train_asr.py:229-248: total = w ctc + (1 - w) att, then backward):
+ *   asr_loss_mix  : out[0] = a[0] wa[0] + b[0] wb[0]  (b, wb may be NULL) - the forward and, with a = grad_output, each branch of the backward;
+ *   asr_scale_dev : out[i] = in[i] alpha[0] - a loss kernel's stored gradient times its grad_output (autograd of CTCLoss / CrossEntropy). */
+int asr_scale_dev(const float* in, float* out, long n, const float* alpha, asr_stream_t stream);
+int asr_loss_mix(const float* a, const float* wa, const float* b, const float* wb, float* out, asr_stream_t stream);
 int asr_status_collect(const void* const* abort_words, int n, unsigned* status, asr_stream_t stream);
 int asr_adadelta_step(float* param, const float* grad, float* square_avg, float* acc_delta, long n,
                       float lr, float rho, float eps, float weight_decay, float clip,

@@ -29,6 +29,17 @@ __device__ __forceinline__ u64 pack2(float a, float b, u64 want) {
 }
 __device__ __forceinline__ float lo_f(u64 g) { return __uint_as_float((unsigned)g & ~7u); }
 __device__ __forceinline__ float hi_f(u64 g) { return __uint_as_float((unsigned)(g >> 32) & ~7u); }
+// four values as IEEE halves in one granule (the context partial sums of the forward records, |x| <= tile frames): the tag keeps
+// its place - bits 0..2 of both words, i.e. the three mantissa LSBs of values 0 and 2 (they keep 8 significant bits, like a
+// bf16; values 1 and 3 all 11) - so gather16 / poll_copy and their masks are unchanged.  A staged word (tag bits cleared by the
+// copy) holds two values: h2f_lo / h2f_hi.
+__device__ __forceinline__ unsigned f2h_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ u64 pack4h(float a, float b, float c, float d, u64 want) {
+    const unsigned lo = (f2h_bits(a) & ~7u) | (f2h_bits(b) << 16), hi = (f2h_bits(c) & ~7u) | (f2h_bits(d) << 16);
+    return ((u64)lo | ((u64)hi << 32)) | want;
+}
+__device__ __forceinline__ float h2f_lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float h2f_hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
 constexpr float NEG_BIG = -1e30f;       // masked energy in the exchange records (-inf would turn into NaN under the tag bit)
 constexpr int NCW = 8, NPW = 4;         // compute waves, polling waves
 constexpr int FSW_NU = 3;               // 16-column units of the forward energy sweep per compute wave (A <= 384)

@@ -414,8 +414,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
             }
             u64* rec = out + (long)NT * (p.HG2 + p.QG2) + (long)j * p.SG2;
             const int ghead = (TE + 2) >> 1;                             // granules of e[TE], m, s
-            if (2 * c2 < E) {
-                if (local) publish<true>(rec + ghead + c2, pack2(x0, x1, want)); else publish<false>(rec + ghead + c2, pack2(x0, x1, want));
+            // context columns 4 at a time as halves (pack4h): the even threads take their neighbour's pair
+            const float y0 = __shfl_down(x0, 1), y1 = __shfl_down(x1, 1);
+            if (2 * c2 < E && (c2 & 1) == 0) {
+                if (local) publish<true>(rec + ghead + (c2 >> 1), pack4h(x0, x1, y0, y1, want)); else publish<false>(rec + ghead + (c2 >> 1), pack4h(x0, x1, y0, y1, want));
             }
             // e pairs, (m, s) and the pad granule by the last compute wave's lanes
             if (wave == NCW - 1) {
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                     if (local) publish<true>(rec + lane, pack2(e0, e1, want)); else publish<false>(rec + lane, pack2(e0, e1, want));
                 } else if (lane == TE / 2) {
                     if (local) publish<true>(rec + lane, pack2(m, ssum, want)); else publish<false>(rec + lane, pack2(m, ssum, want));
-                } else if (lane == TE / 2 + 1 && ghead + E / 2 < p.SG2) {
+                } else if (lane == TE / 2 + 1 && ghead + E / 4 < p.SG2) {
                     u64* dst = rec + p.SG2 - 1;
                     if (local) publish<true>(dst, pack2(0.f, 0.f, want)); else publish<false>(dst, pack2(0.f, 0.f, want));
                 }
@@ -451,11 +453,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_persist(PD p) {
                 s_attp[Ks + tau] = av;
                 if (i == j) p.s.att[row * Tp + tau] = av;
             }
-            for (int c = tz; c < E; c += 64 * NCW) {
-                float acc = 0.f;
-                for (int i = 0; i < NT; ++i) acc += s_stage[i * SG2f + TE + 2 + c] * s_scale[wave][i];
-                s_x[c] = acc;
-                if (c >= c_base && c < c_base + p.CPW) p.s.xin[row * XW + Dd + c] = acc;
+            for (int c2_ = tz; 2 * c2_ < E; c2_ += 64 * NCW) {           // two columns per staged word (halves, pack4h)
+                float a0 = 0.f, a1 = 0.f;
+                for (int i = 0; i < NT; ++i) {
+                    const unsigned w_ = __float_as_uint(s_stage[i * SG2f + TE + 2 + c2_]);
+                    a0 += h2f_lo(w_) * s_scale[wave][i]; a1 += h2f_hi(w_) * s_scale[wave][i];
+                }
+                const int c = 2 * c2_;
+                s_x[c] = a0; s_x[c + 1] = a1;
+                if (c >= c_base && c < c_base + p.CPW) p.s.xin[row * XW + Dd + c] = a0;
+                if (c + 1 >= c_base && c + 1 < c_base + p.CPW) p.s.xin[row * XW + Dd + c + 1] = a1;
             }
         }
         DP_MARK(9)
@@ -564,7 +571,7 @@ PersistPlan persist_plan(const asr_dec_dims_t& d) {
     pl.UPW = cdiv(d.Dd, pl.NT); pl.QPW = cdiv(d.A, pl.NT); pl.CPW = cdiv(d.E, pl.NT);
     if (pl.UPW > 64 || cdiv(4 * pl.UPW, NCW) > 60) return pl;
     auto even = [](int x) { return (x + 1) & ~1; };
-    pl.HG2 = even((pl.UPW + 1) / 2); pl.QG2 = even((pl.QPW + 1) / 2); pl.SG2 = even((pl.TE + 2 + d.E) / 2);
+    pl.HG2 = even((pl.UPW + 1) / 2); pl.QG2 = even((pl.QPW + 1) / 2); pl.SG2 = even((pl.TE + 2) / 2 + d.E / 4);      // record: e pairs, (m, s), context as halves
     pl.KC = d.E + d.Dd; pl.KCP = (pl.KC + 7) & ~7;
     const int taps = 2 * d.Ks + 1;
     size_t fl = 0;

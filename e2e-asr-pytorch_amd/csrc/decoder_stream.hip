@@ -426,11 +426,11 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
             compute_barrier(&s_bar, gen);                               // s_cpart complete
             u64* rec = out + (long)NT * (p.HG2 + p.QG2) + (long)j * p.SG2;
             const int ghead = (TEB + 2) >> 1;                            // granules of e[TEB], m, s
-            const int c2 = tz;
-            if (2 * c2 < E) {
-                float x0 = 0.f, x1 = 0.f;
-                for (int g = 0; g < NG; ++g) { const float2 v = *reinterpret_cast<const float2*>(s_cpart + g * E + 2 * c2); x0 += v.x; x1 += v.y; }
-                if (local) publish<true>(rec + ghead + c2, pack2(x0, x1, want)); else publish<false>(rec + ghead + c2, pack2(x0, x1, want));
+            const int c4 = tz;                                           // four context columns per granule, as halves (pack4h)
+            if (4 * c4 < E) {
+                float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+                for (int g = 0; g < NG; ++g) { const float4 v = *reinterpret_cast<const float4*>(s_cpart + g * E + 4 * c4); x0 += v.x; x1 += v.y; x2 += v.z; x3 += v.w; }
+                if (local) publish<true>(rec + ghead + c4, pack4h(x0, x1, x2, x3, want)); else publish<false>(rec + ghead + c4, pack4h(x0, x1, x2, x3, want));
             }
             for (int i = tz; i < (TEB >> 1); i += 64 * NCW) {
                 const float2 e2 = *reinterpret_cast<const float2*>(s_e + 2 * i);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
             }
             if (tz == 64 * NCW - 1) {
                 if (local) publish<true>(rec + (TEB >> 1), pack2(m, ssum, want)); else publish<false>(rec + (TEB >> 1), pack2(m, ssum, want));
-                if (ghead + E / 2 < p.SG2) {
+                if (ghead + E / 4 < p.SG2) {
                     if (local) publish<true>(rec + p.SG2 - 1, pack2(0.f, 0.f, want)); else publish<false>(rec + p.SG2 - 1, pack2(0.f, 0.f, want));
                 }
             }
@@ -464,11 +464,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW)) void dec_fwd_stream(PSF p) {
                 s_attp[Ks + tau] = av;
                 if (i == j) p.s.att[row * Tp + tau] = av;
             }
-            for (int c = tz; c < E; c += 64 * NCW) {
-                float acc = 0.f;
-                for (int i = 0; i < NT; ++i) acc += s_stage[i * SG2f + TEB + 2 + c] * s_scale[wave][i];
-                s_x[c] = acc;
-                if (c >= c_base && c < c_base + p.CPW) p.s.xin[row * XW + Dd + c] = acc;
+            for (int c2_ = tz; 2 * c2_ < E; c2_ += 64 * NCW) {           // two columns per staged word (halves, pack4h)
+                float a0 = 0.f, a1 = 0.f;
+                for (int i = 0; i < NT; ++i) {
+                    const unsigned w_ = __float_as_uint(s_stage[i * SG2f + TEB + 2 + c2_]);
+                    a0 += h2f_lo(w_) * s_scale[wave][i]; a1 += h2f_hi(w_) * s_scale[wave][i];
+                }
+                const int c = 2 * c2_;
+                s_x[c] = a0; s_x[c + 1] = a1;
+                if (c >= c_base && c < c_base + p.CPW) p.s.xin[row * XW + Dd + c] = a0;
+                if (c + 1 >= c_base && c + 1 < c_base + p.CPW) p.s.xin[row * XW + Dd + c + 1] = a1;
             }
         }
         DP_MARK(10)
@@ -604,7 +609,7 @@ StreamPlanF stream_plan_f(const asr_dec_dims_t& d) {
     pl.UPW = cdiv(d.Dd, pl.NT); pl.QPW = cdiv(d.A, pl.NT); pl.CPW = cdiv(d.E, pl.NT);
     if (pl.UPW > 120 || cdiv(4 * pl.UPW, NCW) > 60) return pl;
     auto even = [](int x) { return (x + 1) & ~1; };
-    pl.HG2 = even((pl.UPW + 1) / 2); pl.QG2 = even((pl.QPW + 1) / 2); pl.SG2 = even((pl.TEB + 2 + d.E) / 2);
+    pl.HG2 = even((pl.UPW + 1) / 2); pl.QG2 = even((pl.QPW + 1) / 2); pl.SG2 = even((pl.TEB + 2) / 2 + d.E / 4);      // record: e pairs, (m, s), context as halves
     pl.KC = d.E + d.Dd; pl.KCP = (pl.KC + 7) & ~7;
     const FCarve c = fwd_carve(pl.TEB, pl.NT, d.A, d.E, d.Kn, d.Ks, pl.KCP, pl.UPW, pl.SG2);
     if (c.NG < 1) return pl;

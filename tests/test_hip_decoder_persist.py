@@ -106,8 +106,10 @@ def test_persistent_backward_matches_step_kernels(B, Tp, L, tiles):
         a, b_ = out[3][n].double(), out[1][n].double()
         assert torch.isfinite(a).all(), n
         if n.endswith('gen_energy.bias'):
-            # analytically zero (softmax is shift invariant): both values are rounding noise
-            assert float(a.abs().max()) < 1e-3 and float(b_.abs().max()) < 1e-3
+            # analytically zero (softmax is shift invariant): sum_t (1 - sum attn_t) dot_t, i.e. fp32 rounding of the attention
+            # rows times the size of dctx . ctx - both values are rounding noise whose sample changes with any rounding upstream
+            # (seen 0.8e-3 .. 1.7e-3 over the forward variants of round 3)
+            assert float(a.abs().max()) < 3e-3 and float(b_.abs().max()) < 3e-3
             continue
         rel = float((a - b_).norm() / (b_.norm() + 1e-12))
         assert rel < 2e-2, '%s: relative difference %g' % (n, rel)

@@ -111,7 +111,7 @@ def test_streamed_backward_matches_step_kernels(B, Tp, L, native):
         a, b_ = out[15][n].double(), out[5][n].double()
         assert torch.isfinite(a).all(), n
         if n.endswith('gen_energy.bias'):
-            assert float(a.abs().max()) < 1e-3 and float(b_.abs().max()) < 1e-3      # analytically zero: rounding noise on both sides
+            assert float(a.abs().max()) < 3e-3 and float(b_.abs().max()) < 3e-3      # analytically zero: rounding noise on both sides (see test_hip_decoder_persist.py)
             continue
         rel = float((a - b_).norm() / (b_.norm() + 1e-12))
         assert rel < 2e-2, '%s: relative difference %g' % (n, rel)

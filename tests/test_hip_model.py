@@ -203,7 +203,9 @@ def test_vgg_front_ends_vs_reference_fixtures(golden_dir, name, prec):
         # bf16 contraction mode: 6 % on the norm; the 4- and 8-channel low band of the frequency-split extractors sums so few
         # products per gradient element that the operand rounding does not average out (measured 10 %): 15 % there
         rel = 5e-4 if f32 else (0.15 if 'low_extractor' in k else 6e-2)
-        tol = rel * r + 1e-5 * gmax
+        # gen_energy.bias has an analytically zero gradient (softmax is shift invariant): its value is fp32 rounding of the attention
+        # rows times dctx . ctx, a noise sample that moves with any rounding upstream - a wider absolute floor for it in bf16 mode
+        tol = rel * r + (1e-5 if (f32 or not k.endswith('gen_energy.bias')) else 4e-5) * gmax
         report.append(('gradnorm.' + k, abs(n - r), tol, abs(n - r) <= tol))
         if f32:
             err = float(np.abs(p.grad.reshape(-1)[:8].cpu().numpy() - z['gradhead.' + k]).max())
